@@ -1,0 +1,207 @@
+/*
+ * rtp_amd.h — C ABI of the MI355X-native path-tracing render library (librtp_amd.so).
+ *
+ * Drop-in boundary: this library replaces the reference's device side of
+ *     void Camera::render(color *d_fb) const        (reference include/camera.cuh:122, src/camera.cu:198-216)
+ * i.e. the launch of render_kernel (src/camera.cu:17-34) and everything it calls
+ * (ray_color src/camera.cu:218-252, hit_scene include/scene.h:23, hit_bvh include/bvh.h:19,
+ * hit_sphere include/sphere.h:24, hit_plane include/plane.h:57, material_scatter
+ * include/materials.h:70, the RNG of include/random_utils.h:7-42).
+ *
+ * The reference passes its inputs through two __constant__ symbols
+ * (d_cam_data_const / d_scene_data_const, src/camera.cu:14-15, written at :291 and :325) whose
+ * scene pointers were cudaMalloc'd by create_scene (src/main.cu:429-474).  Here the same data are
+ * passed explicitly: rt_scene_create() takes the host arrays create_scene builds, in the reference's
+ * own struct layouts, and rt_render() takes the 76-byte CameraData the reference uploads per frame.
+ *
+ * Plain C types only; caller owns every buffer; no function exits the process
+ * (the reference's checkCudaErrors calls exit(99), include/camera.cuh:20-29 — the host-side
+ * mirror in ray-tracing-practice_amd/host reproduces that behaviour on top of these status codes).
+ */
+#ifndef RTP_AMD_H
+#define RTP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = 1,   /* null pointer, negative count, index out of range in the scene */
+    RT_ERR_NO_DEVICE = 2,     /* no HIP device / device ordinal out of range */
+    RT_ERR_HIP = 3,           /* a HIP runtime call failed; see rt_get_last_error_string() */
+    RT_ERR_UNSUPPORTED = 4,   /* scene exceeds a documented limit of this build */
+    RT_ERR_OUT_OF_MEMORY = 5
+} rt_status;
+
+/* ---- reference data layouts (sizes/offsets measured on the reference's headers, x86-64) --- */
+
+/* vec3 / point3 / color: include/vec3.h:18 — three packed floats, 12 bytes. */
+typedef struct rt_vec3 { float e[3]; } rt_vec3;
+
+/* SphereData: include/sphere.h:8-14 — __align__(16), 32 bytes. */
+typedef struct rt_sphere {
+    rt_vec3 center;        /* +0  */
+    float   radius;        /* +12 */
+    int32_t material_idx;  /* +16 */
+    int32_t _pad[3];       /* +20 (alignment tail of the reference struct) */
+} rt_sphere;
+
+/* PlaneType: include/plane.h:7. */
+enum { RT_PLANE_QUAD = 0, RT_PLANE_ELLIPSE = 1, RT_PLANE_TRIANGLE = 2 };
+
+/* PlaneData: include/plane.h:9-17 — __align__(16), 80 bytes.  normal, D and w are the values
+ * the reference's host-only constructor precomputes (include/plane.h:19-28). */
+typedef struct rt_plane {
+    int32_t type;          /* +0  */
+    float   D;             /* +4  dot(normal, base) */
+    int32_t material_idx;  /* +8  */
+    rt_vec3 w;             /* +12 n / dot(n,n), n = cross(u,v) */
+    rt_vec3 u;             /* +24 */
+    rt_vec3 v;             /* +36 */
+    rt_vec3 base;          /* +48 */
+    rt_vec3 normal;        /* +60 unit_vector(n) */
+    int32_t _pad[2];       /* +72 */
+} rt_plane;
+
+/* MaterialType: include/materials.h:12. */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3 };
+
+/* MaterialData: include/materials.h:53-62 — 64 bytes.  The reference's two trailing handles
+ * (cudaTextureObject_t tex_obj at +48, CpuTexture* cpu_tex at +56) are process-local; here +48
+ * holds a 1-based index into rt_scene_desc.textures (0 = untextured) and +56 is reserved (0). */
+typedef struct rt_material {
+    int32_t  type;         /* +0  */
+    float    fuzz;         /* +4  */
+    float    ir;           /* +8  */
+    rt_vec3  absorption;   /* +12 */
+    rt_vec3  albedo;       /* +24 */
+    rt_vec3  emit;         /* +36 */
+    uint64_t texture_id;   /* +48 */
+    uint64_t reserved;     /* +56 */
+} rt_material;
+
+/* BVHNode: include/bvh.h:7-12 — 36 bytes: AABB as x.min,x.max,y.min,y.max,z.min,z.max
+ * (include/aabb.h:8, include/interval.h:7-8) then left,right,type.  Leaf <=> left < 0, then
+ * right = primitive index and type = 0 sphere / 1 plane; internal nodes carry type = -1
+ * (include/bvh_builder.h:61-64,92-94).  Pre-order array, root = node 0. */
+typedef struct rt_bvh_node {
+    float   box[6];
+    int32_t left, right, type;
+} rt_bvh_node;
+
+/* CameraData: include/camera.cuh:86-95 — 76 bytes. */
+typedef struct rt_camera_data {
+    rt_vec3 origin;
+    rt_vec3 pixel00_loc;
+    rt_vec3 pixel_delta_u;
+    rt_vec3 pixel_delta_v;
+    rt_vec3 background;
+    int32_t image_width;
+    int32_t image_height;
+    int32_t samples_per_pixel;
+    int32_t max_depth;
+} rt_camera_data;
+
+/* CpuTexture: include/materials.h:14-18 — float RGBA rows, top row first (stbi_loadf(...,4),
+ * src/main.cu:52-60).  Sampling follows tex2D_cpu (include/materials.h:20-51): gfx950 has no
+ * texture units, so the device does the same software bilinear fetch from a linear buffer. */
+typedef struct rt_texture {
+    const float *rgba;
+    int32_t width, height;
+} rt_texture;
+
+/* What the reference keeps in SceneData + BVHTree (include/scene.h:9-21, include/bvh.h:14-17). */
+typedef struct rt_scene_desc {
+    const rt_sphere   *spheres;   int32_t num_spheres;
+    const rt_plane    *planes;    int32_t num_planes;
+    const rt_material *materials; int32_t num_materials;
+    const rt_bvh_node *nodes;     int32_t num_nodes;     /* the one BVH tree of the scene */
+    const rt_texture  *textures;  int32_t num_textures;
+} rt_scene_desc;
+
+/* Which rows of the image one call renders.  Rows are grouped into bands of band_rows rows;
+ * band b belongs to part (b % num_parts).  The call renders the rows of `part` and writes them
+ * compacted, in increasing row order, into the output buffer (rt_shard_rows() rows of width
+ * image_width).  {0,1,0} or a null pointer = the whole image. */
+typedef struct rt_shard {
+    int32_t band_rows;
+    int32_t num_parts;
+    int32_t part;
+} rt_shard;
+
+typedef struct rt_timing {
+    float    kernel_ms;       /* hipEvent time around the render kernel on the given stream */
+    uint32_t num_workgroups;
+    uint32_t workgroup_size;
+    uint32_t lds_bytes;
+    uint32_t scene_in_lds;    /* 1 when the whole traversal structure is LDS-resident */
+} rt_timing;
+
+typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */
+
+/* ---- entry points -------------------------------------------------------------------------- */
+
+/* Select the HIP device this thread's subsequent calls use (hipSetDevice). */
+rt_status rt_set_device(int32_t device_ordinal);
+
+/* Replaces create_scene's upload block (src/main.cu:429-474) and gpu_render's
+ * cudaMemcpyToSymbol(d_scene_data_const) (src/camera.cu:291): validates the arrays, repacks them
+ * to the device layout and uploads them once. */
+rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene);
+
+/* Replaces destroy_scene_arrays / destroy_texture_resources (src/main.cu:235-246,322-344). */
+rt_status rt_scene_destroy(rt_scene *scene);
+
+/* Number of rows rt_render writes for (image_height, shard). */
+int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard);
+
+/* Replaces cudaMemcpyToSymbol(d_cam_data_const) + render_kernel<<<>>> + cudaDeviceSynchronize
+ * (src/camera.cu:325,204-206).  d_fb_sum is DEVICE memory, rt_shard_rows()*image_width*3 floats,
+ * row-major; like the reference's framebuffer it receives the SUM over samples_per_pixel of the
+ * per-sample radiance, added in sample order (src/camera.cu:27-33).  hip_stream is a hipStream_t
+ * (NULL = default stream).  With sync != 0 the call waits for the kernel and fills `timing`
+ * (may be NULL); with sync == 0 it only enqueues (timing->kernel_ms is then read later with
+ * rt_last_kernel_ms()). */
+rt_status rt_render(rt_scene *scene, const rt_camera_data *cam, const rt_shard *shard,
+                    float *d_fb_sum, void *hip_stream, int32_t sync, rt_timing *timing);
+
+/* Milliseconds of the most recent rt_render kernel of this scene (waits for it). */
+rt_status rt_last_kernel_ms(rt_scene *scene, float *ms);
+
+/* Convenience for hosts without their own device allocator: the whole of Camera::render up to
+ * and including its cudaMemcpy D2H (src/camera.cu:198-209) into a HOST buffer. */
+rt_status rt_render_to_host(rt_scene *scene, const rt_camera_data *cam, const rt_shard *shard,
+                            float *h_fb_sum, rt_timing *timing);
+
+/* Per-sample probe used by the parity tests: for n (i, j, s) triples (ijs = 3*n int32) returns the
+ * radiance ray_color returns for that sample (3*n floats), the number of rays traced (n int32)
+ * and the RNG state after the path (n uint32).  All pointers are HOST memory. */
+rt_status rt_trace_samples(rt_scene *scene, const rt_camera_data *cam, int32_t n, const int32_t *ijs,
+                           float *radiance, int32_t *rays, uint32_t *final_seed);
+
+/* Device buffer management for hosts that do not link the HIP runtime themselves: replace
+ * gpu_render's cudaMalloc / cudaFree of the framebuffer (src/camera.cu:295,348) and
+ * Camera::render's cudaMemcpy device→host (src/camera.cu:209). */
+rt_status rt_device_alloc(uint64_t bytes, void **out_device_ptr);
+rt_status rt_device_free(void *device_ptr);
+rt_status rt_copy_to_host(void *host_dst, const void *device_src, uint64_t bytes);
+
+/* Device-side saver arithmetic ("next" row f1; ISaver::writeColor, src/camera.cu:138-153):
+ * d_rgb8[k] = u8(256*clamp(sqrt(d_fb_sum[k] * (1/divisor)),0,0.999)).  Device pointers. */
+rt_status rt_tonemap(const float *d_fb_sum, uint8_t *d_rgb8, int64_t num_floats, int32_t divisor,
+                     void *hip_stream);
+
+/* Thread-local text of the last failing call ("" if none). */
+const char *rt_get_last_error_string(void);
+
+/* Build identification: "rtp_amd <version> gfx950 parity=<0|1>". */
+const char *rt_version_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTP_AMD_H */

@@ -1,0 +1,268 @@
+"""ctypes bindings of the product libraries (no oracle in here).
+
+librtp_host.so  — pure host code: config parser, scene/BVH builders, camera, saver arithmetic
+                  (ray-tracing-practice_amd/host/rtp_host.h).  Loads without a GPU.
+librtp_amd.so   — the MI355X render library behind the C ABI of include/rtp_amd.h.  Loading it
+                  needs the HIP runtime; every compute call needs a GPU and fails loudly without
+                  one (there is no CPU fallback in the product).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Vec3(C.Structure):
+    _fields_ = [("e", C.c_float * 3)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center", Vec3), ("radius", C.c_float), ("material_idx", C.c_int32), ("_pad", C.c_int32 * 3)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("type", C.c_int32), ("D", C.c_float), ("material_idx", C.c_int32), ("w", Vec3), ("u", Vec3),
+                ("v", Vec3), ("base", Vec3), ("normal", Vec3), ("_pad", C.c_int32 * 2)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("fuzz", C.c_float), ("ir", C.c_float), ("absorption", Vec3), ("albedo", Vec3),
+                ("emit", Vec3), ("texture_id", C.c_uint64), ("reserved", C.c_uint64)]
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("box", C.c_float * 6), ("left", C.c_int32), ("right", C.c_int32), ("type", C.c_int32)]
+
+
+class CameraData(C.Structure):
+    _fields_ = [("origin", Vec3), ("pixel00_loc", Vec3), ("pixel_delta_u", Vec3), ("pixel_delta_v", Vec3),
+                ("background", Vec3), ("image_width", C.c_int32), ("image_height", C.c_int32),
+                ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba", C.POINTER(C.c_float)), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("spheres", C.POINTER(Sphere)), ("num_spheres", C.c_int32),
+                ("planes", C.POINTER(Plane)), ("num_planes", C.c_int32),
+                ("materials", C.POINTER(Material)), ("num_materials", C.c_int32),
+                ("nodes", C.POINTER(BvhNode)), ("num_nodes", C.c_int32),
+                ("textures", C.POINTER(Texture)), ("num_textures", C.c_int32)]
+
+
+class Shard(C.Structure):
+    _fields_ = [("band_rows", C.c_int32), ("num_parts", C.c_int32), ("part", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("kernel_ms", C.c_float), ("num_workgroups", C.c_uint32), ("workgroup_size", C.c_uint32),
+                ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32)]
+
+
+class ConfigInfo(C.Structure):
+    _fields_ = [("num_frames", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32),
+                ("sqrt_spp", C.c_int32), ("fov_degrees", C.c_float)]
+
+
+assert C.sizeof(Sphere) == 32 and C.sizeof(Plane) == 80 and C.sizeof(Material) == 64
+assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
+
+# Every symbol include/rtp_amd.h declares (tests check that the library exports all of them).
+RTP_AMD_SYMBOLS = [
+    "rt_set_device", "rt_scene_create", "rt_scene_destroy", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
+    "rt_render_to_host", "rt_trace_samples", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
+    "rt_get_last_error_string", "rt_version_string",
+]
+
+_host = None
+_amd = None
+
+
+def host_lib():
+    """librtp_host.so (pure host)."""
+    global _host
+    if _host is None:
+        path = os.path.join(_HERE, "librtp_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (or make -C ray-tracing-practice_amd)")
+        lib = C.CDLL(path)
+        lib.rtp_host_scene_from_config.restype = C.c_void_p
+        lib.rtp_host_scene_from_config.argtypes = [C.c_char_p, C.c_char_p]
+        lib.rtp_host_scene_rtiow.restype = C.c_void_p
+        lib.rtp_host_scene_rtiow.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32]
+        lib.rtp_host_scene_free.argtypes = [C.c_void_p]
+        lib.rtp_host_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        lib.rtp_host_scene_config.argtypes = [C.c_void_p, C.POINTER(ConfigInfo)]
+        lib.rtp_host_frame_camera.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CameraData)]
+        lib.rtp_host_make_camera.argtypes = [C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                             C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(CameraData)]
+        lib.rtp_host_quantize.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        lib.rtp_host_write_binary_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.rtp_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.rtp_host_default_config.restype = C.c_char_p
+        _host = lib
+    return _host
+
+
+def amd_lib():
+    """librtp_amd.so (HIP).  Raises if the library is not built — there is no fallback."""
+    global _amd
+    if _amd is None:
+        path = os.path.join(_HERE, "librtp_amd.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: the HIP render library must be built (no CPU fallback exists)")
+        lib = C.CDLL(path)
+        lib.rt_set_device.argtypes = [C.c_int32]
+        lib.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        lib.rt_scene_destroy.argtypes = [C.c_void_p]
+        lib.rt_shard_rows.argtypes = [C.c_int32, C.POINTER(Shard)]
+        lib.rt_shard_rows.restype = C.c_int32
+        lib.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.POINTER(Timing)]
+        lib.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.rt_render_to_host.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p,
+                                          C.POINTER(Timing)]
+        lib.rt_trace_samples.argtypes = [C.c_void_p, C.POINTER(CameraData), C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+        lib.rt_device_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+        lib.rt_device_free.argtypes = [C.c_void_p]
+        lib.rt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        lib.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        lib.rt_get_last_error_string.restype = C.c_char_p
+        lib.rt_version_string.restype = C.c_char_p
+        _amd = lib
+    return _amd
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _check(status, what):
+    if status != 0:
+        msg = amd_lib().rt_get_last_error_string().decode()
+        raise RtError(f"{what} failed with rt_status {status}: {msg}")
+
+
+class HostScene:
+    """Host-side scene (arrays in the reference's layouts) built by librtp_host.so."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("host scene construction failed")
+        self._h = C.c_void_p(handle)
+        self.desc = SceneDesc()
+        host_lib().rtp_host_scene_desc(self._h, C.byref(self.desc))
+        self.info = ConfigInfo()
+        host_lib().rtp_host_scene_config(self._h, C.byref(self.info))
+
+    @classmethod
+    def from_config(cls, text, texture_dir=""):
+        return cls(host_lib().rtp_host_scene_from_config(text.encode(), (texture_dir or "").encode()))
+
+    @classmethod
+    def rtiow(cls, seed=12345, half_extent=11, textured_quad=False, texture_size=1024):
+        return cls(host_lib().rtp_host_scene_rtiow(seed, half_extent, int(textured_quad), texture_size))
+
+    def frame_camera(self, frame=0):
+        cam = CameraData()
+        host_lib().rtp_host_frame_camera(self._h, frame, C.byref(cam))
+        return cam
+
+    def nodes_array(self):
+        n = self.desc.num_nodes
+        return np.ctypeslib.as_array(C.cast(self.desc.nodes, C.POINTER(C.c_int32)), shape=(n, 9)).copy()
+
+    def close(self):
+        if self._h:
+            host_lib().rtp_host_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_camera(width, height, vfov, eye, target, background=(0, 0, 0), spp=1, max_depth=50):
+    cam = CameraData()
+    f3 = C.c_float * 3
+    host_lib().rtp_host_make_camera(width, height, vfov, f3(*eye), f3(*target), f3(*background), spp, max_depth,
+                                    C.byref(cam))
+    return cam
+
+
+def rtiow_camera(width, height, spp, max_depth=50):
+    """Benchmark camera of SURVEY.md §8(d): from (13,3,2) at the origin, vfov 20, sky (0.7,0.8,1.0)."""
+    return make_camera(width, height, 20.0, (13, 3, 2), (0, 0, 0), (0.7, 0.8, 1.0), spp, max_depth)
+
+
+def quantize(fb_sum, divisor):
+    fb = np.ascontiguousarray(fb_sum, dtype=np.float32)
+    out = np.empty(fb.size, dtype=np.uint8)
+    host_lib().rtp_host_quantize(fb.ctypes.data, fb.size // 3, divisor, out.ctypes.data)
+    return out.reshape(fb.shape)
+
+
+def binary_image_bytes(fb_sum, width, height, divisor):
+    """Bytes of the file BinarySaver writes (src/camera.cu:128-153)."""
+    return np.array([width, height], dtype=np.int32).tobytes() + quantize(fb_sum, divisor).tobytes()
+
+
+class DeviceScene:
+    """rt_scene handle (device-resident repacked scene)."""
+
+    def __init__(self, host_scene, device=None):
+        lib = amd_lib()
+        if device is not None:
+            _check(lib.rt_set_device(device), "rt_set_device")
+        self._h = C.c_void_p()
+        _check(lib.rt_scene_create(C.byref(host_scene.desc), C.byref(self._h)), "rt_scene_create")
+        self._keep = host_scene
+
+    def render_to_host(self, cam, shard=None):
+        lib = amd_lib()
+        rows = lib.rt_shard_rows(cam.image_height, C.byref(shard) if shard else None)
+        fb = np.empty((rows, cam.image_width, 3), dtype=np.float32)
+        t = Timing()
+        _check(lib.rt_render_to_host(self._h, C.byref(cam), C.byref(shard) if shard else None, fb.ctypes.data,
+                                     C.byref(t)), "rt_render_to_host")
+        return fb, t
+
+    def render(self, cam, d_fb_ptr, shard=None, stream=None, sync=True):
+        """d_fb_ptr: integer device address (e.g. torch tensor.data_ptr())."""
+        t = Timing()
+        _check(amd_lib().rt_render(self._h, C.byref(cam), C.byref(shard) if shard else None, C.c_void_p(d_fb_ptr),
+                                   C.c_void_p(stream or 0), 1 if sync else 0, C.byref(t)), "rt_render")
+        return t
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(amd_lib().rt_last_kernel_ms(self._h, C.byref(ms)), "rt_last_kernel_ms")
+        return ms.value
+
+    def trace_samples(self, cam, ijs):
+        ijs = np.ascontiguousarray(ijs, dtype=np.int32).reshape(-1, 3)
+        n = ijs.shape[0]
+        rad = np.empty((n, 3), dtype=np.float32)
+        rays = np.empty(n, dtype=np.int32)
+        seeds = np.empty(n, dtype=np.uint32)
+        _check(amd_lib().rt_trace_samples(self._h, C.byref(cam), n, ijs.ctypes.data, rad.ctypes.data, rays.ctypes.data,
+                                          seeds.ctypes.data), "rt_trace_samples")
+        return rad, rays, seeds
+
+    def close(self):
+        if self._h:
+            amd_lib().rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
