@@ -1,0 +1,259 @@
+#include "rt_accel.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+namespace rtaccel {
+namespace {
+
+inline float bits_as_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+
+struct LeafRef {
+    float box[6];   // x.min x.max y.min y.max z.min z.max — the reference layout
+    int32_t code;
+};
+
+struct BuildNode {
+    float box[6];
+    int32_t child[2];   // codes
+};
+
+void box_union(const float a[6], const float b[6], float out[6]) {
+    for (int k = 0; k < 3; ++k) {
+        out[2 * k] = fminf(a[2 * k], b[2 * k]);
+        out[2 * k + 1] = fmaxf(a[2 * k + 1], b[2 * k + 1]);
+    }
+}
+
+float half_area(const float b[6]) {
+    const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Top-down SAH build over the leaf boxes (sweep on all three axes; N log^2 N).  Only the
+// topology differs from the caller's tree: boxes are exact unions of the same leaf boxes.
+struct SahBuilder {
+    std::vector<LeafRef> &leaves;
+    std::vector<BuildNode> nodes;
+    std::vector<float> right_area;
+
+    explicit SahBuilder(std::vector<LeafRef> &l) : leaves(l) {}
+
+    int32_t build(int first, int last, float out_box[6]) {
+        if (last - first == 1) {
+            std::memcpy(out_box, leaves[first].box, sizeof(float) * 6);
+            return leaves[first].code;
+        }
+        const int n = last - first;
+        int best_axis = -1, best_split = -1;
+        float best_cost = INFINITY;
+        for (int axis = 0; axis < 3; ++axis) {
+            std::sort(leaves.begin() + first, leaves.begin() + last, [axis](const LeafRef &a, const LeafRef &b) {
+                return a.box[2 * axis] + a.box[2 * axis + 1] < b.box[2 * axis] + b.box[2 * axis + 1];
+            });
+            right_area.resize(static_cast<size_t>(n));
+            float acc[6];
+            std::memcpy(acc, leaves[last - 1].box, sizeof(acc));
+            for (int k = n - 1; k >= 1; --k) {
+                box_union(acc, leaves[first + k].box, acc);
+                right_area[static_cast<size_t>(k)] = half_area(acc);
+            }
+            std::memcpy(acc, leaves[first].box, sizeof(acc));
+            for (int k = 1; k < n; ++k) {
+                box_union(acc, leaves[first + k - 1].box, acc);
+                const float cost = half_area(acc) * k + right_area[static_cast<size_t>(k)] * (n - k);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = k; }
+            }
+        }
+        if (best_axis < 0) { best_axis = 0; best_split = n / 2; }
+        if (best_axis != 2) {
+            const int axis = best_axis;
+            std::sort(leaves.begin() + first, leaves.begin() + last, [axis](const LeafRef &a, const LeafRef &b) {
+                return a.box[2 * axis] + a.box[2 * axis + 1] < b.box[2 * axis] + b.box[2 * axis + 1];
+            });
+        }
+        const int32_t me = static_cast<int32_t>(nodes.size());
+        nodes.push_back(BuildNode{});
+        float lb[6], rb[6];
+        const int32_t l = build(first, first + best_split, lb);
+        const int32_t r = build(first + best_split, last, rb);
+        nodes[static_cast<size_t>(me)].child[0] = l;
+        nodes[static_cast<size_t>(me)].child[1] = r;
+        box_union(lb, rb, out_box);
+        std::memcpy(nodes[static_cast<size_t>(me)].box, out_box, sizeof(float) * 6);
+        return me;
+    }
+};
+
+}  // namespace
+
+std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
+    out = Packed{};
+    if (d.num_spheres < 0 || d.num_planes < 0 || d.num_materials < 0 || d.num_nodes < 0 || d.num_textures < 0)
+        return "negative element count";
+    if ((d.num_spheres && !d.spheres) || (d.num_planes && !d.planes) || (d.num_materials && !d.materials) ||
+        (d.num_nodes && !d.nodes) || (d.num_textures && !d.textures))
+        return "null array with non-zero count";
+    if (d.num_spheres > (1 << 29) || d.num_planes > (1 << 29)) return "too many primitives";
+
+    for (int i = 0; i < d.num_spheres; ++i)
+        if (d.spheres[i].material_idx < 0 || d.spheres[i].material_idx >= d.num_materials)
+            return "sphere material index out of range";
+    for (int i = 0; i < d.num_planes; ++i) {
+        if (d.planes[i].material_idx < 0 || d.planes[i].material_idx >= d.num_materials)
+            return "plane material index out of range";
+    }
+    for (int i = 0; i < d.num_materials; ++i) {
+        if (d.materials[i].texture_id > static_cast<uint64_t>(d.num_textures)) return "material texture id out of range";
+        if (d.materials[i].type < 0 || d.materials[i].type > 3) return "unknown material type";
+    }
+    for (int i = 0; i < d.num_textures; ++i)
+        if (!d.textures[i].rgba || d.textures[i].width <= 0 || d.textures[i].height <= 0) return "bad texture";
+
+    // ---- leaves of the caller's tree, validated to be a tree in pre-order (children after parent)
+    std::vector<LeafRef> leaves;
+    std::vector<int32_t> depth(static_cast<size_t>(d.num_nodes), 0);
+    std::vector<char> reachable(static_cast<size_t>(d.num_nodes), 0);
+    if (d.num_nodes > 0) reachable[0] = 1;
+    for (int k = 0; k < d.num_nodes; ++k) {
+        const rt_bvh_node &n = d.nodes[k];
+        if (!reachable[static_cast<size_t>(k)]) continue;   // unreachable entries are never visited by hit_bvh
+        if (n.left < 0) {
+            if (n.type == 0) {
+                if (n.right < 0 || n.right >= d.num_spheres) return "leaf sphere index out of range";
+            } else if (n.type == 1) {
+                if (n.right < 0 || n.right >= d.num_planes) return "leaf plane index out of range";
+            } else {
+                continue;   // leaf of unknown type: the reference tests nothing there (include/bvh.h:39-43)
+            }
+            LeafRef lr;
+            std::memcpy(lr.box, n.box, sizeof(lr.box));
+            lr.code = leaf_code(n.right, n.type);
+            leaves.push_back(lr);
+        } else {
+            if (n.left <= k || n.left >= d.num_nodes || n.right <= k || n.right >= d.num_nodes)
+                return "BVH nodes must be in pre-order (children after their parent, inside the array)";
+            if (reachable[static_cast<size_t>(n.left)] || reachable[static_cast<size_t>(n.right)] || n.left == n.right)
+                return "BVH node referenced twice";
+            reachable[static_cast<size_t>(n.left)] = reachable[static_cast<size_t>(n.right)] = 1;
+            depth[static_cast<size_t>(n.left)] = depth[static_cast<size_t>(n.right)] = depth[static_cast<size_t>(k)] + 1;
+        }
+    }
+
+    // ---- traversal tree
+    std::vector<BuildNode> bnodes;
+    if (leaves.empty()) {
+        out.root = kTraversalDone;
+    } else if (mode == TreeMode::Sah || d.nodes[0].left < 0) {
+        SahBuilder b(leaves);
+        float rb[6];
+        out.root = b.build(0, static_cast<int>(leaves.size()), rb);
+        bnodes = std::move(b.nodes);
+    } else {
+        // same topology as the caller's tree: internal node k → dense index, in array order
+        std::vector<int32_t> dense(static_cast<size_t>(d.num_nodes), -1);
+        int32_t count = 0;
+        for (int k = 0; k < d.num_nodes; ++k)
+            if (reachable[static_cast<size_t>(k)] && d.nodes[k].left >= 0) dense[static_cast<size_t>(k)] = count++;
+        bnodes.resize(static_cast<size_t>(count));
+        auto code_of = [&](int32_t k) -> int32_t {
+            const rt_bvh_node &c = d.nodes[k];
+            if (c.left >= 0) return dense[static_cast<size_t>(k)];
+            if (c.type == 0 || c.type == 1) return leaf_code(c.right, c.type);
+            return kTraversalDone;   // untyped leaf: never hit
+        };
+        for (int k = 0; k < d.num_nodes; ++k) {
+            if (dense[static_cast<size_t>(k)] < 0) continue;
+            BuildNode &bn = bnodes[static_cast<size_t>(dense[static_cast<size_t>(k)])];
+            std::memcpy(bn.box, d.nodes[k].box, sizeof(bn.box));
+            bn.child[0] = code_of(d.nodes[k].left);
+            bn.child[1] = code_of(d.nodes[k].right);
+        }
+        out.root = 0;
+    }
+
+    // ---- child-pair node table
+    // box of a child code: leaf → its exact leaf box; internal → that node's box
+    std::vector<const float *> sphere_box(static_cast<size_t>(d.num_spheres), nullptr), plane_box(static_cast<size_t>(d.num_planes), nullptr);
+    for (const LeafRef &l : leaves) {
+        const int32_t c = -(l.code + 1);
+        if (c & 1) plane_box[static_cast<size_t>(c >> 1)] = l.box; else sphere_box[static_cast<size_t>(c >> 1)] = l.box;
+    }
+    const float empty_box[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};   // never hit
+    auto box_of = [&](int32_t code) -> const float * {
+        if (code == kTraversalDone) return empty_box;
+        if (code >= 0) return bnodes[static_cast<size_t>(code)].box;
+        const int32_t c = -(code + 1);
+        return (c & 1) ? plane_box[static_cast<size_t>(c >> 1)] : sphere_box[static_cast<size_t>(c >> 1)];
+    };
+    out.num_internal = static_cast<int32_t>(bnodes.size());
+    out.nodes.resize(bnodes.size() * 16);
+    for (size_t k = 0; k < bnodes.size(); ++k) {
+        float *o = &out.nodes[k * 16];
+        const float *b0 = box_of(bnodes[k].child[0]);
+        const float *b1 = box_of(bnodes[k].child[1]);
+        // lo0.xyz hi0.xyz lo1.xyz hi1.xyz
+        o[0] = b0[0]; o[1] = b0[2]; o[2] = b0[4]; o[3] = b0[1]; o[4] = b0[3]; o[5] = b0[5];
+        o[6] = b1[0]; o[7] = b1[2]; o[8] = b1[4]; o[9] = b1[1]; o[10] = b1[3]; o[11] = b1[5];
+        o[12] = bits_as_float(bnodes[k].child[0]);
+        o[13] = bits_as_float(bnodes[k].child[1]);
+        o[14] = 0; o[15] = 0;
+    }
+    // depth of the traversal tree (stack bound: one entry per level at most)
+    {
+        int32_t maxd = 0;
+        std::function<void(int32_t, int32_t)> walk = [&](int32_t code, int32_t dep) {
+            if (code < 0) { maxd = std::max(maxd, dep); return; }
+            walk(bnodes[static_cast<size_t>(code)].child[0], dep + 1);
+            walk(bnodes[static_cast<size_t>(code)].child[1], dep + 1);
+        };
+        if (out.root != kTraversalDone) walk(out.root, 0);
+        out.max_depth = maxd;
+    }
+
+    // ---- primitive and material tables
+    out.spheres.resize(static_cast<size_t>(d.num_spheres) * 4);
+    out.sphere_mat.resize(static_cast<size_t>(d.num_spheres));
+    for (int i = 0; i < d.num_spheres; ++i) {
+        float *o = &out.spheres[static_cast<size_t>(i) * 4];
+        o[0] = d.spheres[i].center.e[0]; o[1] = d.spheres[i].center.e[1]; o[2] = d.spheres[i].center.e[2];
+        o[3] = d.spheres[i].radius;
+        out.sphere_mat[static_cast<size_t>(i)] = d.spheres[i].material_idx;
+    }
+    out.planes.resize(static_cast<size_t>(d.num_planes) * 20);
+    for (int i = 0; i < d.num_planes; ++i) {
+        const rt_plane &p = d.planes[i];
+        float *o = &out.planes[static_cast<size_t>(i) * 20];
+        o[0] = p.normal.e[0]; o[1] = p.normal.e[1]; o[2] = p.normal.e[2]; o[3] = p.D;
+        o[4] = p.w.e[0]; o[5] = p.w.e[1]; o[6] = p.w.e[2]; o[7] = bits_as_float(p.type);
+        o[8] = p.u.e[0]; o[9] = p.u.e[1]; o[10] = p.u.e[2]; o[11] = bits_as_float(p.material_idx);
+        o[12] = p.v.e[0]; o[13] = p.v.e[1]; o[14] = p.v.e[2]; o[15] = 0;
+        o[16] = p.base.e[0]; o[17] = p.base.e[1]; o[18] = p.base.e[2]; o[19] = 0;
+    }
+    out.materials.resize(static_cast<size_t>(d.num_materials) * 16);
+    for (int i = 0; i < d.num_materials; ++i) {
+        const rt_material &m = d.materials[i];
+        float *o = &out.materials[static_cast<size_t>(i) * 16];
+        o[0] = bits_as_float(m.type); o[1] = m.fuzz; o[2] = m.ir; o[3] = bits_as_float(static_cast<int32_t>(m.texture_id));
+        o[4] = m.absorption.e[0]; o[5] = m.absorption.e[1]; o[6] = m.absorption.e[2]; o[7] = 0;
+        o[8] = m.albedo.e[0]; o[9] = m.albedo.e[1]; o[10] = m.albedo.e[2]; o[11] = 0;
+        o[12] = m.emit.e[0]; o[13] = m.emit.e[1]; o[14] = m.emit.e[2]; o[15] = 0;
+    }
+    size_t texels = 0;
+    for (int i = 0; i < d.num_textures; ++i) {
+        const rt_texture &t = d.textures[i];
+        out.tex_info.push_back(static_cast<int32_t>(texels));
+        out.tex_info.push_back(t.width);
+        out.tex_info.push_back(t.height);
+        out.tex_info.push_back(0);
+        const size_t n = static_cast<size_t>(t.width) * t.height;
+        if (texels + n > (1u << 30)) return "textures too large";
+        out.tex_data.insert(out.tex_data.end(), t.rgba, t.rgba + n * 4);
+        texels += n;
+    }
+    return "";
+}
+
+}  // namespace rtaccel

@@ -1,0 +1,44 @@
+// rt_accel.h — host-side repacking of the reference's scene arrays into the device layout.
+//
+// Input: the arrays of rt_scene_desc (reference layouts).  Output: flat float4 tables the kernel
+// stages into LDS:
+//   nodes      4 x float4 per INTERNAL node ("child-pair" form): the two child boxes and two child
+//              codes, so one traversal step reads 64 B and tests both children;
+//              child code >= 0 → internal node index, < 0 → leaf, -(2*prim_index + prim_type) - 1.
+//   spheres    1 x float4: center.xyz, radius;  sphere_mat: int per sphere
+//   planes     5 x float4: (normal, D) (w, type) (u, material) (v, 0) (base, 0)
+//   materials  4 x float4: (type, fuzz, ir, texture_id) (absorption) (albedo) (emit)
+// Leaf boxes are copied bit for bit from the caller's BVH leaves — they are the gate the
+// reference applies before each primitive test (include/bvh.h:36-37), so the set of primitives a
+// ray can hit is the same; inner boxes are exact fmin/fmax unions of leaf boxes.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/rtp_amd.h"
+
+namespace rtaccel {
+
+constexpr int32_t kTraversalDone = INT32_MIN;   // "no more nodes" sentinel of the traversal
+
+inline int32_t leaf_code(int32_t prim_index, int32_t prim_type) { return -(2 * prim_index + prim_type) - 1; }
+
+struct Packed {
+    std::vector<float> nodes;      // 16 floats per internal node
+    std::vector<float> spheres;    // 4 per sphere
+    std::vector<int32_t> sphere_mat;
+    std::vector<float> planes;     // 20 per plane
+    std::vector<float> materials;  // 16 per material
+    std::vector<float> tex_data;   // RGBA floats of all textures, concatenated
+    std::vector<int32_t> tex_info; // 4 per texture: float offset (in float4 units), width, height, 0
+    int32_t root = kTraversalDone; // node code of the root (leaf code when the scene has one primitive)
+    int32_t num_internal = 0;
+    int32_t max_depth = 0;         // longest root→leaf path in internal nodes = traversal stack bound
+};
+
+enum class TreeMode { Reference, Sah };
+
+// Returns "" on success, else a message (→ RT_ERR_INVALID_ARG).
+std::string pack_scene(const rt_scene_desc &desc, TreeMode mode, Packed &out);
+
+}  // namespace rtaccel

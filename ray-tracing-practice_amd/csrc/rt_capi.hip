@@ -1,0 +1,332 @@
+// rt_capi.hip — implementation of the C ABI in include/rtp_amd.h on top of the gfx950 kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rtp_amd.h"
+#include "rt_accel.h"
+#include "rt_device_math.h"
+#include "rt_kernel.hip.inc"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+rt_status fail(rt_status st, const std::string &msg) {
+    g_last_error = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                   \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+    } while (0)
+
+int env_int(const char *name, int fallback) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : fallback;
+}
+
+constexpr uint32_t kLdsLimit = 160 * 1024;
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
+    int32_t *sphere_mat = nullptr;
+    int4 *tex_info = nullptr;
+    uint32_t *queue = nullptr;
+    int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    int num_cus = 0;
+};
+
+namespace {
+
+template <class T>
+rt_status upload(const std::vector<T> &host, void **dev) {
+    *dev = nullptr;
+    if (host.empty()) return RT_OK;
+    HIP_TRY(hipMalloc(dev, host.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+void normalise_shard(const rt_shard *in, int32_t height, rt_shard &out) {
+    if (!in || in->num_parts <= 1 || in->band_rows <= 0) {
+        out.band_rows = height > 0 ? height : 1;
+        out.num_parts = 1;
+        out.part = 0;
+    } else {
+        out = *in;
+    }
+}
+
+rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, rtk::KParams &P) {
+    std::memset(&P, 0, sizeof(P));
+    if (!sc || !cam) return fail(RT_ERR_INVALID_ARG, "null scene or camera");
+    if (cam->image_width <= 0 || cam->image_height <= 0) return fail(RT_ERR_INVALID_ARG, "image size must be positive");
+    if (shard && shard->num_parts > 1 && (shard->part < 0 || shard->part >= shard->num_parts || shard->band_rows <= 0))
+        return fail(RT_ERR_INVALID_ARG, "bad shard");
+    std::memcpy(P.origin, cam->origin.e, 12);
+    std::memcpy(P.p00, cam->pixel00_loc.e, 12);
+    std::memcpy(P.du, cam->pixel_delta_u.e, 12);
+    std::memcpy(P.dv, cam->pixel_delta_v.e, 12);
+    std::memcpy(P.bg, cam->background.e, 12);
+    P.width = cam->image_width;
+    P.height = cam->image_height;
+    P.spp = cam->samples_per_pixel;
+    P.max_depth = cam->max_depth;
+    rt_shard s;
+    normalise_shard(shard, cam->image_height, s);
+    P.band_rows = s.band_rows;
+    P.num_parts = s.num_parts;
+    P.part = s.part;
+    P.local_rows = rt_shard_rows(cam->image_height, shard);
+    P.nodes = sc->nodes; P.num_internal = sc->num_internal; P.root = sc->root;
+    P.spheres = sc->spheres; P.num_spheres = sc->num_spheres;
+    P.planes = sc->planes; P.num_planes = sc->num_planes;
+    P.materials = sc->materials; P.num_materials = sc->num_materials;
+    P.sphere_mat = sc->sphere_mat;
+    P.tex_data = sc->tex_data; P.tex_info = sc->tex_info;
+    P.queue = sc->queue;
+    P.tiles_x = (P.width + 7) / 8;
+    P.total_work = (uint32_t)P.tiles_x * (uint32_t)((P.local_rows + 7) / 8) * 64u;
+    P.stack_levels = sc->tree_depth + 1;
+    if (P.stack_levels < 2) P.stack_levels = 2;
+    P.k_inner = env_int("RTP_K_INNER", 40);
+    P.k_shade = env_int("RTP_K_SHADE", 16);
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_get_last_error_string(void) { return g_last_error.c_str(); }
+
+const char *rt_version_string(void) { return "rtp_amd 0.1 gfx950 parity=1"; }
+
+rt_status rt_set_device(int32_t device_ordinal) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(RT_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    return RT_OK;
+}
+
+rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
+    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARG, "null argument");
+    *out_scene = nullptr;
+    rtaccel::Packed pk;
+    const char *tree = getenv("RTP_TREE");
+    const rtaccel::TreeMode mode = (tree && std::string(tree) == "ref") ? rtaccel::TreeMode::Reference : rtaccel::TreeMode::Sah;
+    const std::string err = rtaccel::pack_scene(*desc, mode, pk);
+    if (!err.empty()) return fail(RT_ERR_INVALID_ARG, err);
+
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
+    rt_scene *sc = new (std::nothrow) rt_scene;
+    if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    rt_status st = RT_OK;
+    auto bail = [&](rt_status s) { rt_scene_destroy(sc); return s; };
+    if (hipGetDevice(&sc->device) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipGetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, sc->device) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
+    sc->num_cus = prop.multiProcessorCount;
+    if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
+    if ((st = upload(pk.spheres, (void **)&sc->spheres)) != RT_OK) return bail(st);
+    if ((st = upload(pk.planes, (void **)&sc->planes)) != RT_OK) return bail(st);
+    if ((st = upload(pk.materials, (void **)&sc->materials)) != RT_OK) return bail(st);
+    if ((st = upload(pk.sphere_mat, (void **)&sc->sphere_mat)) != RT_OK) return bail(st);
+    if ((st = upload(pk.tex_data, (void **)&sc->tex_data)) != RT_OK) return bail(st);
+    if ((st = upload(pk.tex_info, (void **)&sc->tex_info)) != RT_OK) return bail(st);
+    if (hipMalloc((void **)&sc->queue, 256) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"));
+    if (hipEventCreate(&sc->ev_start) != hipSuccess || hipEventCreate(&sc->ev_stop) != hipSuccess)
+        return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
+    sc->num_internal = pk.num_internal;
+    sc->num_spheres = (int32_t)pk.sphere_mat.size();
+    sc->num_planes = (int32_t)(pk.planes.size() / 20);
+    sc->num_materials = (int32_t)(pk.materials.size() / 16);
+    sc->root = pk.root;
+    sc->tree_depth = pk.max_depth;
+    *out_scene = sc;
+    return RT_OK;
+}
+
+rt_status rt_scene_destroy(rt_scene *sc) {
+    if (!sc) return RT_OK;
+    (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
+    (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue);
+    if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
+    if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
+    delete sc;
+    return RT_OK;
+}
+
+int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard) {
+    if (image_height <= 0) return 0;
+    if (!shard || shard->num_parts <= 1 || shard->band_rows <= 0) return image_height;
+    const int64_t band = shard->band_rows, parts = shard->num_parts, part = shard->part;
+    if (part < 0 || part >= parts) return 0;
+    const int64_t cycle = band * parts;
+    const int64_t full = image_height / cycle, rem = image_height % cycle;
+    int64_t rows = full * band;
+    const int64_t start = part * band;
+    if (rem > start) rows += (rem - start < band) ? rem - start : band;
+    return (int32_t)rows;
+}
+
+rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, float *d_fb_sum, void *hip_stream,
+                    int32_t sync, rt_timing *timing) {
+    rtk::KParams P;
+    rt_status st = fill_params(sc, cam, shard, P);
+    if (st != RT_OK) return st;
+    if (!d_fb_sum) return fail(RT_ERR_INVALID_ARG, "null framebuffer");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    P.fb = d_fb_sum;
+    if (timing) std::memset(timing, 0, sizeof(*timing));
+    const size_t fb_bytes = (size_t)P.local_rows * P.width * 3 * sizeof(float);
+    if (P.local_rows == 0) return RT_OK;
+    if (P.spp <= 0 || P.max_depth <= 0) {     // the reference's loops add nothing: all-zero sums
+        HIP_TRY(hipMemsetAsync(d_fb_sum, 0, fb_bytes, stream));
+        if (sync) HIP_TRY(hipStreamSynchronize(stream));
+        sc->timed = false;
+        return RT_OK;
+    }
+
+    const uint32_t waves = rtk::kBlock / rtk::kWave;
+    const uint32_t stack_bytes = waves * (uint32_t)P.stack_levels * rtk::kWave * 4u;
+    const uint64_t scene_bytes = ((uint64_t)P.num_internal * 4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5) * 16;
+    const bool in_lds = !env_int("RTP_NO_LDS_SCENE", 0) && scene_bytes + stack_bytes <= kLdsLimit;
+    const uint32_t lds_bytes = (uint32_t)(in_lds ? scene_bytes + stack_bytes : stack_bytes);
+    if (lds_bytes > kLdsLimit) return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
+    int wgs = sc->num_cus * env_int("RTP_WGS_PER_CU", 1);
+    const uint32_t max_wgs = (P.total_work + rtk::kBlock - 1) / rtk::kBlock;
+    if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
+    if (wgs < 1) wgs = 1;
+
+    HIP_TRY(hipMemsetAsync(sc->queue, 0, 4, stream));
+    HIP_TRY(hipEventRecord(sc->ev_start, stream));
+    if (in_lds) {
+        HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(rtk::render_kernel<true>, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(rtk::render_kernel<false>, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sc->ev_stop, stream));
+    sc->timed = true;
+    if (timing) {
+        timing->num_workgroups = (uint32_t)wgs;
+        timing->workgroup_size = rtk::kBlock;
+        timing->lds_bytes = lds_bytes;
+        timing->scene_in_lds = in_lds ? 1u : 0u;
+    }
+    if (sync) {
+        HIP_TRY(hipEventSynchronize(sc->ev_stop));
+        if (timing) HIP_TRY(hipEventElapsedTime(&timing->kernel_ms, sc->ev_start, sc->ev_stop));
+    }
+    return RT_OK;
+}
+
+rt_status rt_last_kernel_ms(rt_scene *sc, float *ms) {
+    if (!sc || !ms) return fail(RT_ERR_INVALID_ARG, "null argument");
+    *ms = 0.0f;
+    if (!sc->timed) return RT_OK;
+    HIP_TRY(hipEventSynchronize(sc->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, sc->ev_start, sc->ev_stop));
+    return RT_OK;
+}
+
+rt_status rt_render_to_host(rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, float *h_fb_sum, rt_timing *timing) {
+    if (!sc || !cam || !h_fb_sum) return fail(RT_ERR_INVALID_ARG, "null argument");
+    const int32_t rows = rt_shard_rows(cam->image_height, shard);
+    const size_t bytes = (size_t)rows * (size_t)(cam->image_width > 0 ? cam->image_width : 0) * 3 * sizeof(float);
+    if (bytes == 0) return RT_OK;
+    float *d_fb = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_fb, bytes));
+    rt_status st = rt_render(sc, cam, shard, d_fb, nullptr, 1, timing);
+    if (st == RT_OK && hipMemcpy(h_fb_sum, d_fb, bytes, hipMemcpyDeviceToHost) != hipSuccess) st = fail(RT_ERR_HIP, "hipMemcpy D2H failed");
+    (void)hipFree(d_fb);
+    return st;
+}
+
+rt_status rt_trace_samples(rt_scene *sc, const rt_camera_data *cam, int32_t n, const int32_t *ijs, float *radiance,
+                           int32_t *rays, uint32_t *final_seed) {
+    if (n < 0 || (n > 0 && (!ijs || !radiance || !rays || !final_seed))) return fail(RT_ERR_INVALID_ARG, "null argument");
+    rtk::KParams P;
+    rt_status st = fill_params(sc, cam, nullptr, P);
+    if (st != RT_OK) return st;
+    if (n == 0) return RT_OK;
+    for (int32_t k = 0; k < n; ++k)
+        if (ijs[3 * k] < 0 || ijs[3 * k] >= cam->image_width || ijs[3 * k + 1] < 0 || ijs[3 * k + 1] >= cam->image_height || ijs[3 * k + 2] < 0)
+            return fail(RT_ERR_INVALID_ARG, "sample coordinate out of range");
+    int32_t *d_ijs = nullptr, *d_rays = nullptr;
+    float *d_rad = nullptr;
+    uint32_t *d_seed = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_ijs); (void)hipFree(d_rays); (void)hipFree(d_rad); (void)hipFree(d_seed); };
+    if (hipMalloc((void **)&d_ijs, (size_t)n * 12) != hipSuccess || hipMalloc((void **)&d_rad, (size_t)n * 12) != hipSuccess ||
+        hipMalloc((void **)&d_rays, (size_t)n * 4) != hipSuccess || hipMalloc((void **)&d_seed, (size_t)n * 4) != hipSuccess) {
+        cleanup();
+        return fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    }
+    if (hipMemcpy(d_ijs, ijs, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(RT_ERR_HIP, "hipMemcpy H2D failed"); }
+    P.probe_ijs = d_ijs; P.probe_rad = d_rad; P.probe_rays = d_rays; P.probe_seed = d_seed; P.probe_n = n;
+    const uint32_t lds = 4u * (uint32_t)P.stack_levels * rtk::kWave * 4u;
+    if (lds > kLdsLimit) { cleanup(); return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack"); }
+    (void)hipFuncSetAttribute((const void *)rtk::probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(rtk::probe_kernel, dim3((n + 255) / 256), dim3(256), lds, 0, P);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(radiance, d_rad, (size_t)n * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(rays, d_rays, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(final_seed, d_seed, (size_t)n * 4, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("probe kernel: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+rt_status rt_device_alloc(uint64_t bytes, void **out) {
+    if (!out) return fail(RT_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (bytes == 0) return RT_OK;
+    HIP_TRY(hipMalloc(out, bytes));
+    return RT_OK;
+}
+
+rt_status rt_device_free(void *p) {
+    if (p) HIP_TRY(hipFree(p));
+    return RT_OK;
+}
+
+rt_status rt_copy_to_host(void *dst, const void *src, uint64_t bytes) {
+    if (bytes == 0) return RT_OK;
+    if (!dst || !src) return fail(RT_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+rt_status rt_tonemap(const float *d_fb_sum, uint8_t *d_rgb8, int64_t num_floats, int32_t divisor, void *hip_stream) {
+    if (num_floats <= 0) return RT_OK;
+    if (!d_fb_sum || !d_rgb8) return fail(RT_ERR_INVALID_ARG, "null argument");
+    const float inv = (float)(1.0 / (double)(float)divisor);     // pixel_color / samplesPerPixel, include/vec3.h:97
+    int64_t blocks = (num_floats + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rtk::tonemap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, d_fb_sum, d_rgb8, num_floats, inv);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // extern "C"
