@@ -106,7 +106,7 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
             return "plane material index out of range";
     }
     for (int i = 0; i < d.num_materials; ++i) {
-        if (d.materials[i].texture_id > static_cast<uint64_t>(d.num_textures)) return "material texture id out of range";
+        if (d.materials[i].texture_id > static_cast<uint64_t>(d.num_textures) || d.materials[i].texture_id >= (1u << 28)) return "material texture id out of range";
         if (d.materials[i].type < 0 || d.materials[i].type > 3) return "unknown material type";
     }
     for (int i = 0; i < d.num_textures; ++i)
@@ -139,6 +139,50 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                 return "BVH node referenced twice";
             reachable[static_cast<size_t>(n.left)] = reachable[static_cast<size_t>(n.right)] = 1;
             depth[static_cast<size_t>(n.left)] = depth[static_cast<size_t>(n.right)] = depth[static_cast<size_t>(k)] + 1;
+        }
+    }
+
+    // ---- threaded copy in the reference's own visit order (iterative DFS, left first)
+    {
+        struct Item { int32_t node; int32_t stack_ptr; };
+        std::vector<Item> todo;
+        std::vector<int32_t> order, subtree_end_slot;
+        std::vector<int32_t> visit_sp;
+        if (d.num_nodes > 0) todo.push_back({0, 0});
+        // first pass: visit order (exactly the pops of hit_bvh, including its silent pruning
+        // when fewer than two stack slots are left, include/bvh.h:51)
+        std::vector<int32_t> pos_of(static_cast<size_t>(d.num_nodes), -1);
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            pos_of[static_cast<size_t>(it.node)] = static_cast<int32_t>(order.size());
+            order.push_back(it.node);
+            visit_sp.push_back(it.stack_ptr);
+            const rt_bvh_node &n = d.nodes[it.node];
+            if (n.left >= 0 && it.stack_ptr + 2 <= 32) {
+                todo.push_back({n.right, it.stack_ptr});       // popped after the whole left subtree
+                todo.push_back({n.left, it.stack_ptr + 1});
+            }
+        }
+        const int32_t count = static_cast<int32_t>(order.size());
+        // skip pointer = position just after the node's subtree: computed backwards
+        std::vector<int32_t> skip(static_cast<size_t>(count), count);
+        for (int32_t p = count - 1; p >= 0; --p) {
+            const rt_bvh_node &n = d.nodes[order[static_cast<size_t>(p)]];
+            const bool expanded = n.left >= 0 && visit_sp[static_cast<size_t>(p)] + 2 <= 32;
+            if (!expanded) skip[static_cast<size_t>(p)] = p + 1;
+            else skip[static_cast<size_t>(p)] = skip[static_cast<size_t>(pos_of[static_cast<size_t>(n.right)])];
+        }
+        out.num_tnodes = count;
+        out.tnodes.resize(static_cast<size_t>(count) * 8);
+        for (int32_t p = 0; p < count; ++p) {
+            const rt_bvh_node &n = d.nodes[order[static_cast<size_t>(p)]];
+            float *o = &out.tnodes[static_cast<size_t>(p) * 8];
+            o[0] = n.box[0]; o[1] = n.box[2]; o[2] = n.box[4]; o[3] = n.box[1]; o[4] = n.box[3]; o[5] = n.box[5];
+            o[6] = bits_as_float(skip[static_cast<size_t>(p)]);
+            int32_t prim = -1;
+            if (n.left < 0 && (n.type == 0 || n.type == 1)) prim = 2 * n.right + n.type;
+            o[7] = bits_as_float(prim);
         }
     }
 
@@ -232,14 +276,14 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
         o[12] = p.v.e[0]; o[13] = p.v.e[1]; o[14] = p.v.e[2]; o[15] = 0;
         o[16] = p.base.e[0]; o[17] = p.base.e[1]; o[18] = p.base.e[2]; o[19] = 0;
     }
-    out.materials.resize(static_cast<size_t>(d.num_materials) * 16);
+    out.materials.resize(static_cast<size_t>(d.num_materials) * 12);
     for (int i = 0; i < d.num_materials; ++i) {
         const rt_material &m = d.materials[i];
-        float *o = &out.materials[static_cast<size_t>(i) * 16];
-        o[0] = bits_as_float(m.type); o[1] = m.fuzz; o[2] = m.ir; o[3] = bits_as_float(static_cast<int32_t>(m.texture_id));
-        o[4] = m.absorption.e[0]; o[5] = m.absorption.e[1]; o[6] = m.absorption.e[2]; o[7] = 0;
-        o[8] = m.albedo.e[0]; o[9] = m.albedo.e[1]; o[10] = m.albedo.e[2]; o[11] = 0;
-        o[12] = m.emit.e[0]; o[13] = m.emit.e[1]; o[14] = m.emit.e[2]; o[15] = 0;
+        float *o = &out.materials[static_cast<size_t>(i) * 12];
+        const int32_t tag = m.type | (static_cast<int32_t>(m.texture_id) << 2);
+        o[0] = m.albedo.e[0]; o[1] = m.albedo.e[1]; o[2] = m.albedo.e[2]; o[3] = bits_as_float(tag);
+        o[4] = m.emit.e[0]; o[5] = m.emit.e[1]; o[6] = m.emit.e[2]; o[7] = m.fuzz;
+        o[8] = m.absorption.e[0]; o[9] = m.absorption.e[1]; o[10] = m.absorption.e[2]; o[11] = m.ir;
     }
     size_t texels = 0;
     for (int i = 0; i < d.num_textures; ++i) {

@@ -7,7 +7,7 @@
 //              child code >= 0 → internal node index, < 0 → leaf, -(2*prim_index + prim_type) - 1.
 //   spheres    1 x float4: center.xyz, radius;  sphere_mat: int per sphere
 //   planes     5 x float4: (normal, D) (w, type) (u, material) (v, 0) (base, 0)
-//   materials  4 x float4: (type, fuzz, ir, texture_id) (absorption) (albedo) (emit)
+//   materials  3 x float4: (albedo, type | texture_id << 2) (emit, fuzz) (absorption, ir)
 // Leaf boxes are copied bit for bit from the caller's BVH leaves — they are the gate the
 // reference applies before each primitive test (include/bvh.h:36-37), so the set of primitives a
 // ray can hit is the same; inner boxes are exact fmin/fmax unions of leaf boxes.
@@ -28,9 +28,15 @@ struct Packed {
     std::vector<float> spheres;    // 4 per sphere
     std::vector<int32_t> sphere_mat;
     std::vector<float> planes;     // 20 per plane
-    std::vector<float> materials;  // 16 per material
+    std::vector<float> materials;  // 12 per material
     std::vector<float> tex_data;   // RGBA floats of all textures, concatenated
     std::vector<int32_t> tex_info; // 4 per texture: float offset (in float4 units), width, height, 0
+    // "Threaded" copy of the caller's tree for reference-order traversal: 8 floats per node, nodes
+    // in the order hit_bvh pops them (left child first, include/bvh.h:52-59): box lo.xyz hi.x |
+    // hi.yz, skip (index of the next node when this subtree is skipped), prim (2*index+type for
+    // a typed leaf, -1 otherwise).  Visiting node k: box hit → next is k+1, miss → next is skip.
+    std::vector<float> tnodes;
+    int32_t num_tnodes = 0;
     int32_t root = kTraversalDone; // node code of the root (leaf code when the scene has one primitive)
     int32_t num_internal = 0;
     int32_t max_depth = 0;         // longest root→leaf path in internal nodes = traversal stack bound

@@ -37,10 +37,21 @@ int env_int(const char *name, int fallback) {
 
 constexpr uint32_t kLdsLimit = 160 * 1024;
 
+// Traversal mode.  "threaded" (default): the caller's tree in the reference's own visit order —
+// results equal the reference's even where they depend on visit order.  "ordered": SAH child-pair
+// tree, near child first — fewer box tests, identical results except for rays where a primitive's
+// computed hit lies in front of its own leaf box (see DESIGN.md "Traversal order").
+bool threaded_mode() {
+    const char *v = getenv("RTP_TRAVERSAL");
+    return !(v && std::string(v) == "ordered");
+}
+
 }  // namespace
 
 struct rt_scene {
     int device = 0;
+    float4 *tnodes = nullptr;
+    int32_t num_tnodes = 0;
     float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
@@ -94,6 +105,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.part = s.part;
     P.local_rows = rt_shard_rows(cam->image_height, shard);
     P.nodes = sc->nodes; P.num_internal = sc->num_internal; P.root = sc->root;
+    P.tnodes = sc->tnodes; P.num_tnodes = sc->num_tnodes;
     P.spheres = sc->spheres; P.num_spheres = sc->num_spheres;
     P.planes = sc->planes; P.num_planes = sc->num_planes;
     P.materials = sc->materials; P.num_materials = sc->num_materials;
@@ -104,8 +116,8 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.total_work = (uint32_t)P.tiles_x * (uint32_t)((P.local_rows + 7) / 8) * 64u;
     P.stack_levels = sc->tree_depth + 1;
     if (P.stack_levels < 2) P.stack_levels = 2;
-    P.k_inner = env_int("RTP_K_INNER", 40);
-    P.k_shade = env_int("RTP_K_SHADE", 16);
+    P.k_inner = env_int("RTP_K_INNER", 24);
+    P.k_shade = env_int("RTP_K_SHADE", 32);
     return RT_OK;
 }
 
@@ -145,6 +157,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (hipGetDeviceProperties(&prop, sc->device) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
     sc->num_cus = prop.multiProcessorCount;
     if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
+    if ((st = upload(pk.tnodes, (void **)&sc->tnodes)) != RT_OK) return bail(st);
+    sc->num_tnodes = pk.num_tnodes;
     if ((st = upload(pk.spheres, (void **)&sc->spheres)) != RT_OK) return bail(st);
     if ((st = upload(pk.planes, (void **)&sc->planes)) != RT_OK) return bail(st);
     if ((st = upload(pk.materials, (void **)&sc->materials)) != RT_OK) return bail(st);
@@ -157,7 +171,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->num_internal = pk.num_internal;
     sc->num_spheres = (int32_t)pk.sphere_mat.size();
     sc->num_planes = (int32_t)(pk.planes.size() / 20);
-    sc->num_materials = (int32_t)(pk.materials.size() / 16);
+    sc->num_materials = (int32_t)(pk.materials.size() / 12);
     sc->root = pk.root;
     sc->tree_depth = pk.max_depth;
     *out_scene = sc;
@@ -166,6 +180,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
 
 rt_status rt_scene_destroy(rt_scene *sc) {
     if (!sc) return RT_OK;
+    (void)hipFree(sc->tnodes);
     (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
@@ -205,26 +220,37 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         return RT_OK;
     }
 
+    const bool threaded = threaded_mode();
     const uint32_t waves = rtk::kBlock / rtk::kWave;
+    if (threaded) P.stack_levels = 0;
     const uint32_t stack_bytes = waves * (uint32_t)P.stack_levels * rtk::kWave * 4u;
-    const uint64_t scene_bytes = ((uint64_t)P.num_internal * 4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5) * 16;
+    const uint64_t node_f4 = threaded ? (uint64_t)P.num_tnodes * 2 : (uint64_t)P.num_internal * 4;
+    const uint64_t scene_bytes = (node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
+                                  ((uint64_t)P.num_spheres + 3) / 4) * 16;
+    // two workgroups per CU when both fit in LDS, else one, else tables stay in global memory
+    int wgs_per_cu = env_int("RTP_WGS_PER_CU", 0);
+    if (wgs_per_cu <= 0) wgs_per_cu = (2 * (scene_bytes + stack_bytes) <= kLdsLimit && 2 * rtk::kBlock <= 2048) ? RTP_MIN_WAVES * 256 / rtk::kBlock : 1;
+    if (wgs_per_cu < 1) wgs_per_cu = 1;
     const bool in_lds = !env_int("RTP_NO_LDS_SCENE", 0) && scene_bytes + stack_bytes <= kLdsLimit;
     const uint32_t lds_bytes = (uint32_t)(in_lds ? scene_bytes + stack_bytes : stack_bytes);
     if (lds_bytes > kLdsLimit) return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
-    int wgs = sc->num_cus * env_int("RTP_WGS_PER_CU", 1);
+    int wgs = sc->num_cus * wgs_per_cu;
     const uint32_t max_wgs = (P.total_work + rtk::kBlock - 1) / rtk::kBlock;
     if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
     if (wgs < 1) wgs = 1;
 
-    HIP_TRY(hipMemsetAsync(sc->queue, 0, 4, stream));
+    HIP_TRY(hipMemsetAsync(sc->queue, 0, 256, stream));
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
-    if (in_lds) {
-        HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(rtk::render_kernel<true>, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
-    } else {
-        HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(rtk::render_kernel<false>, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
-    }
+    auto launch = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
+        return hipSuccess;
+    };
+    if (in_lds && threaded) HIP_TRY(launch(rtk::render_kernel<true, true>));
+    else if (in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>));
+    else if (threaded) HIP_TRY(launch(rtk::render_kernel<false, true>));
+    else HIP_TRY(launch(rtk::render_kernel<false, false>));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_stop, stream));
     sc->timed = true;
@@ -238,6 +264,14 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         HIP_TRY(hipEventSynchronize(sc->ev_stop));
         if (timing) HIP_TRY(hipEventElapsedTime(&timing->kernel_ms, sc->ev_start, sc->ev_stop));
     }
+    return RT_OK;
+}
+
+// Developer hook (not part of the ABI header): raw counters of an RTP_STATS build.
+rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[8]) {
+    if (!sc || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, sc->queue + 8, 32, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -286,8 +320,12 @@ rt_status rt_trace_samples(rt_scene *sc, const rt_camera_data *cam, int32_t n, c
     P.probe_ijs = d_ijs; P.probe_rad = d_rad; P.probe_rays = d_rays; P.probe_seed = d_seed; P.probe_n = n;
     const uint32_t lds = 4u * (uint32_t)P.stack_levels * rtk::kWave * 4u;
     if (lds > kLdsLimit) { cleanup(); return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack"); }
-    (void)hipFuncSetAttribute((const void *)rtk::probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(rtk::probe_kernel, dim3((n + 255) / 256), dim3(256), lds, 0, P);
+    if (threaded_mode()) {
+        hipLaunchKernelGGL(rtk::probe_kernel<true>, dim3((n + 255) / 256), dim3(256), lds, 0, P);
+    } else {
+        (void)hipFuncSetAttribute((const void *)rtk::probe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(rtk::probe_kernel<false>, dim3((n + 255) / 256), dim3(256), lds, 0, P);
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(radiance, d_rad, (size_t)n * 12, hipMemcpyDeviceToHost);

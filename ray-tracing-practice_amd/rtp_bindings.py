@@ -112,7 +112,8 @@ def amd_lib():
     """librtp_amd.so (HIP).  Raises if the library is not built — there is no fallback."""
     global _amd
     if _amd is None:
-        path = os.path.join(_HERE, "librtp_amd.so")
+        # RTP_AMD_LIB: developer override used by tools/ to A/B differently compiled kernels
+        path = os.environ.get("RTP_AMD_LIB") or os.path.join(_HERE, "librtp_amd.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP render library must be built (no CPU fallback exists)")
         lib = C.CDLL(path)

@@ -1,0 +1,56 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ray-tracing-practice_amd")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, PKG)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_libraries():
+    """Make sure the in-tree libraries exist (they are git-ignored build products)."""
+    needed = [os.path.join(PKG, "librtp_amd.so"), os.path.join(PKG, "librtp_host.so"),
+              os.path.join(ROOT, "oracle", "librt_oracle.so")]
+    if not all(os.path.exists(p) for p in needed):
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
+
+
+@pytest.fixture(scope="session")
+def test_config_text():
+    with open(os.path.join(ROOT, "tests", "golden", "test_config.txt")) as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "survey_pins.json")) as f:
+        return json.load(f)

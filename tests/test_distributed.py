@@ -1,0 +1,53 @@
+"""N > 1 path on CPU: world_size-2 gloo processes each render their interleaved row bands (the
+oracle stands in for the GPU render, which needs a GPU) and one gather assembles the frame on
+rank 0; the result must equal the single-process frame bit for bit."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, height, band, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "ray-tracing-practice_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frame_parallel as fp
+    import oracle_bindings as ob
+    import rtp_bindings as rb
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host = rb.HostScene.rtiow()
+    cam = rb.rtiow_camera(48, height, 2, 8)
+    rows = fp.shard_row_indices(height, band, world, rank)
+    shard = fp.shard_for_rank(rank, world, band)
+    assert rb.amd_lib().rt_shard_rows(height, shard) == len(rows)
+    full = ob.render(host, cam)          # every rank could render everything; it keeps only its rows
+    local = torch.from_numpy(np.ascontiguousarray(full[rows]))
+    frame = fp.gather_frame(local, height, band)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+        np.save(out_path + ".ref.npy", full)
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, height, band, tmp_path, port):
+    out = str(tmp_path / f"frame_{world}_{height}_{band}.npy")
+    mp.spawn(_worker, args=(world, port, height, band, out), nprocs=world, join=True)
+    got, want = np.load(out), np.load(out + ".ref.npy")
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_two_rank_gather_reassembles_frame(tmp_path):
+    _run(2, 40, 8, tmp_path, 29611)
+
+
+def test_ragged_bands_three_ranks(tmp_path):
+    _run(3, 37, 4, tmp_path, 29612)      # 37 rows, bands of 4 over 3 ranks: unequal row counts, partial last band

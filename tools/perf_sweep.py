@@ -1,0 +1,23 @@
+"""Dev tool: kernel time of the rtiow frame under the env knobs given on the command line."""
+import os, sys, time
+sys.path.insert(0,'tests'); sys.path.insert(0,'ray-tracing-practice_amd')
+import rtp_bindings as rb, numpy as np
+W,H,SPP=int(os.environ.get('W',1920)),int(os.environ.get('H',1080)),int(os.environ.get('SPP',16))
+hs=rb.HostScene.rtiow(half_extent=int(os.environ.get('EXT',11)))
+cam=rb.rtiow_camera(W,H,SPP,50)
+ds=rb.DeviceScene(hs,device=0)
+best=1e9
+for it in range(int(os.environ.get('ITERS',4))):
+    fb,tm=ds.render_to_host(cam); best=min(best,tm.kernel_ms)
+print('cfg', {k:v for k,v in os.environ.items() if k.startswith('RTP_')}, 'best kernel ms %.3f'%best, 'Msamples/s %.1f'%(W*H*SPP/best/1e3), 'lds',tm.lds_bytes,'wgs',tm.num_workgroups, 'sum', float(fb.sum()))
+
+import ctypes as C
+lib=rb.amd_lib()
+if os.environ.get('STATS'):
+    out=(C.c_uint32*8)()
+    lib.rt_debug_read_stats(ds._h, out)
+    names=['inner','leaf','shadephase','shade']
+    ns=W*H*SPP
+    for k,n in enumerate(names):
+        it,ln=out[2*k],out[2*k+1]
+        print('  %-10s wave-steps %10d  full-wave-equiv %10d  util %.3f  per-sample lane-steps %.2f'%(n,it,ln,ln/max(it,1), ln*64/ns))
