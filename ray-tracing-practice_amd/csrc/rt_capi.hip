@@ -268,10 +268,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
 }
 
 // Developer hook (not part of the ABI header): raw counters of an RTP_STATS build.
-rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[8]) {
+rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[12]) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, sc->queue + 8, 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, sc->queue + 8, 48, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

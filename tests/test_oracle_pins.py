@@ -72,6 +72,37 @@ def test_reference_image_sha256(test_config_text, golden):
                           rb.quantize(fb[:5], hs.info.sqrt_spp))
 
 
+def test_textured_reference_image_sha256(golden, tmp_path):
+    """Second full-image pin: the reference's config.txt shrunk to 400x225, depth
+    10, 4^2 spp with floor.jpg as the floor texture.  Covers tex2D_cpu, the textured METAL floor
+    and the polyhedra at a second resolution.  floor.jpg is decoded by the reference's OWN vendored
+    stb_image.h, compiled where it lies by oracle/Makefile target `_ref`; this needs /root/reference,
+    so the test runs in the build container only."""
+    import os
+    import subprocess
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "floor.jpg")):
+        pytest.skip("reference tree not present (GPU box)")
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "_ref"], check=True, capture_output=True)
+    pfm = str(tmp_path / "floor.pfm")
+    subprocess.run([os.path.join(root, "oracle", "_ref", "stb_decode"), os.path.join(ref, "floor.jpg"), pfm], check=True)
+    lines = open(os.path.join(ref, "config.txt")).read().split("\n")
+    while not lines[-1].strip():
+        lines.pop()
+    lines[0] = "1"
+    lines[2] = "400 225 50"
+    lines[8] = lines[8].replace("../floor2.jpg", pfm)
+    lines[-1] = "10 4"
+    hs = rb.HostScene.from_config("\n".join(lines) + "\n")
+    assert hs.desc.num_textures == 1 and hs.desc.textures[0].width == 2000 and hs.desc.textures[0].height == 1330
+    cam = hs.frame_camera(0)
+    fb = ob.render(hs, cam, threads=8)
+    data = rb.binary_image_bytes(fb, 400, 225, hs.info.sqrt_spp)
+    assert hashlib.sha256(data).hexdigest() == golden["config_txt_400x225_d10_spp16_floor_jpg_sha256"]
+
+
 def test_threaded_render_equals_serial(test_config_text):
     hs = rb.HostScene.from_config(test_config_text)
     cam = hs.frame_camera(0)

@@ -14,10 +14,11 @@ print('cfg', {k:v for k,v in os.environ.items() if k.startswith('RTP_')}, 'best 
 import ctypes as C
 lib=rb.amd_lib()
 if os.environ.get('STATS'):
-    out=(C.c_uint32*8)()
+    out=(C.c_uint32*12)()
     lib.rt_debug_read_stats(ds._h, out)
     names=['inner','leaf','shadephase','shade']
     ns=W*H*SPP
     for k,n in enumerate(names):
         it,ln=out[2*k],out[2*k+1]
-        print('  %-10s wave-steps %10d  full-wave-equiv %10d  util %.3f  per-sample lane-steps %.2f'%(n,it,ln,ln/max(it,1), ln*64/ns))
+        print('  %-10s kticks %9d'%(n,out[8+k]) if k<4 else '', end=' ')
+        print(' wave-steps %10d  full-wave-equiv %10d  util %.3f  per-sample lane-steps %.2f'%(it,ln,ln/max(it,1), ln*64/ns))
