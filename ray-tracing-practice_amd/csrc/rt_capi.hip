@@ -36,6 +36,7 @@ int env_int(const char *name, int fallback) {
 }
 
 constexpr uint32_t kLdsLimit = 160 * 1024;
+constexpr int kMaxPasses = 1024;        // 64 samples per pass
 
 // Traversal mode.  "threaded" (default): the caller's tree in the reference's own visit order —
 // results equal the reference's even where they depend on visit order.  "ordered": SAH child-pair
@@ -55,7 +56,9 @@ struct rt_scene {
     float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
-    uint32_t *queue = nullptr;
+    uint32_t *queue = nullptr;      // kMaxPasses work counters + 16 developer-stat words
+    float4 *slab = nullptr;         // per-sample radiance workspace of one pass, grown on demand
+    size_t slab_float4s = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
@@ -112,12 +115,22 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.sphere_mat = sc->sphere_mat;
     P.tex_data = sc->tex_data; P.tex_info = sc->tex_info;
     P.queue = sc->queue;
-    P.tiles_x = (P.width + 7) / 8;
-    P.total_work = (uint32_t)P.tiles_x * (uint32_t)((P.local_rows + 7) / 8) * 64u;
+    P.tiles_x = 0;
+    if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "more than 2^25 pixels per call");
+    P.slot_shift = 6;
+    while (P.slot_shift > 0 && (1 << (P.slot_shift - 1)) >= P.spp) P.slot_shift--;     // next power of two >= spp, at most 64
+    P.total_work = ((uint32_t)P.local_rows * (uint32_t)P.width) << P.slot_shift;
+    P.stats = sc->queue + kMaxPasses;
     P.stack_levels = sc->tree_depth + 1;
     if (P.stack_levels < 2) P.stack_levels = 2;
     P.k_inner = env_int("RTP_K_INNER", 24);
-    P.k_shade = env_int("RTP_K_SHADE", 32);
+    P.k_shade = env_int("RTP_K_SHADE", 40);
+    {   // ~1024 samples per reserved range: 64 pixels at 16 spp, exact-need at >= 1024 spp
+        int refill = P.spp > 0 ? 1024 / P.spp : 64;
+        if (refill > 64) refill = 64;
+        if (refill < 1) refill = 1;
+        P.pool_refill = (uint32_t)env_int("RTP_POOL_REFILL", refill);
+    }
     return RT_OK;
 }
 
@@ -165,7 +178,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if ((st = upload(pk.sphere_mat, (void **)&sc->sphere_mat)) != RT_OK) return bail(st);
     if ((st = upload(pk.tex_data, (void **)&sc->tex_data)) != RT_OK) return bail(st);
     if ((st = upload(pk.tex_info, (void **)&sc->tex_info)) != RT_OK) return bail(st);
-    if (hipMalloc((void **)&sc->queue, 256) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"));
+    if (hipMalloc((void **)&sc->queue, (kMaxPasses + 16) * 4) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"));
     if (hipEventCreate(&sc->ev_start) != hipSuccess || hipEventCreate(&sc->ev_stop) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
     sc->num_internal = pk.num_internal;
@@ -182,7 +195,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     if (!sc) return RT_OK;
     (void)hipFree(sc->tnodes);
     (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
-    (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue);
+    (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
     delete sc;
@@ -223,7 +236,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     const bool threaded = threaded_mode();
     const uint32_t waves = rtk::kBlock / rtk::kWave;
     if (threaded) P.stack_levels = 0;
-    const uint32_t stack_bytes = waves * (uint32_t)P.stack_levels * rtk::kWave * 4u;
+    const uint32_t stack_bytes = waves * (uint32_t)P.stack_levels * rtk::kWave * 4u + waves * 8u;   // + per-wave pixel ranges
     const uint64_t node_f4 = threaded ? (uint64_t)P.num_tnodes * 2 : (uint64_t)P.num_internal * 4;
     const uint64_t scene_bytes = (node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
                                   ((uint64_t)P.num_spheres + 3) / 4) * 16;
@@ -235,22 +248,46 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     const uint32_t lds_bytes = (uint32_t)(in_lds ? scene_bytes + stack_bytes : stack_bytes);
     if (lds_bytes > kLdsLimit) return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
     int wgs = sc->num_cus * wgs_per_cu;
-    const uint32_t max_wgs = (P.total_work + rtk::kBlock - 1) / rtk::kBlock;
+    const uint32_t max_wgs = (uint32_t)(((uint64_t)P.local_rows * P.width * (P.spp < 64 ? P.spp : 64) + rtk::kBlock - 1) / rtk::kBlock);
     if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
     if (wgs < 1) wgs = 1;
 
-    HIP_TRY(hipMemsetAsync(sc->queue, 0, 256, stream));
+    // workspace: one float4 per (local pixel, slot)
+    const size_t need = (size_t)P.total_work;
+    if (sc->slab_float4s < need) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(sc->slab);
+        sc->slab = nullptr;
+        sc->slab_float4s = 0;
+        HIP_TRY(hipMalloc((void **)&sc->slab, need * sizeof(float4)));
+        sc->slab_float4s = need;
+    }
+    P.slab = sc->slab;
+    const int passes = (P.spp + 63) / 64;
+    if (passes > kMaxPasses) return fail(RT_ERR_UNSUPPORTED, "samples_per_pixel above 65536");
+    const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
+
+    HIP_TRY(hipMemsetAsync(sc->queue, 0, (kMaxPasses + 16) * 4, stream));
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
     auto launch = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
-        return hipSuccess;
+        return hipGetLastError();
     };
-    if (in_lds && threaded) HIP_TRY(launch(rtk::render_kernel<true, true>));
-    else if (in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>));
-    else if (threaded) HIP_TRY(launch(rtk::render_kernel<false, true>));
-    else HIP_TRY(launch(rtk::render_kernel<false, false>));
+    for (int pass = 0; pass < passes; ++pass) {
+        // samples [64*pass, 64*pass + count) of every pixel, traced in any order into the slab …
+        P.pass_first = pass * 64;
+        P.pass_count = P.spp - P.pass_first < 64 ? P.spp - P.pass_first : 64;
+        P.queue = sc->queue + pass;
+        if (in_lds && threaded) HIP_TRY(launch(rtk::render_kernel<true, true>));
+        else if (in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>));
+        else if (threaded) HIP_TRY(launch(rtk::render_kernel<false, true>));
+        else HIP_TRY(launch(rtk::render_kernel<false, false>));
+        // … then added to the pixel sums strictly in sample order
+        hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 255) / 256), dim3(256), 0, stream, d_fb_sum,
+                           (const float4 *)sc->slab, num_pixels, P.pass_count, pass == 0 ? 1 : 0, P.slot_shift);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_stop, stream));
     sc->timed = true;
@@ -271,7 +308,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
 rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[12]) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, sc->queue + 8, 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, sc->queue + kMaxPasses, 48, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
