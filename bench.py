@@ -106,13 +106,16 @@ def main():
     fb = torch.zeros((local_rows, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
 
-    kernel_ms = []
+    kernel_ms, trace_ms, launches = [], [], []
 
     def step(record):
         dev.render(cam, fb.data_ptr(), shard=shard, stream=stream, sync=False)
         frame = fp.gather_frame(fb, HEIGHT, band) if world > 1 else fb
         if record:
-            kernel_ms.append(dev.last_kernel_ms())      # hipEvent pair recorded on `stream` around the kernel
+            t = dev.last_timing()     # hipEvent pairs recorded on `stream`: whole call, and around each trace launch
+            kernel_ms.append(t.kernel_ms)
+            trace_ms.append(t.trace_ms)
+            launches.append(t.trace_launches)
         return frame
 
     def fence():
@@ -167,18 +170,24 @@ def main():
         bytes_per_sample = st.bytes_per_sample(args.spp) if st is not None else 5790.0   # SURVEY.md §8(d) if not re-counted
         local_samples = local_rows * WIDTH * args.spp
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        achieved = bytes_per_sample * local_samples / (k_ms * 1e-3) / 1e9
+        tr_ms = float(np.mean(trace_ms)) if trace_ms else float("nan")
+        n_launch = int(launches[0]) if launches else 0
+        # one frame = n_launch launches of the trace kernel (64 samples per pixel each);
+        # achieved = algorithmic bytes of one launch / its mean duration
+        launch_ms = tr_ms / max(n_launch, 1)
+        achieved = bytes_per_sample * (local_samples / max(n_launch, 1)) / (launch_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch_1920x1080x500")
+                traffic = json.load(open(tpath)).get("bytes_per_trace_launch_1920x1080x64")
             except Exception:
                 traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "rtk::render_kernel", "kernel_ms": round(k_ms, 3),
+            "kernel": "rtk::render_kernel<true,true>", "launches_per_step": n_launch, "launch_ms": round(launch_ms, 3),
+            "step_kernels_ms": round(k_ms, 3),
             "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
             "note": "algorithmic bytes (node/sphere/material records the reference's traversal touches) are served "
                     "from LDS, not HBM; see DESIGN.md 'Roofline' for the VALU-side reading",

@@ -134,11 +134,13 @@ typedef struct rt_shard {
 } rt_shard;
 
 typedef struct rt_timing {
-    float    kernel_ms;       /* hipEvent time around the render kernel on the given stream */
+    float    kernel_ms;       /* hipEvent time from the first to after the last kernel of the call, on the given stream */
     uint32_t num_workgroups;
     uint32_t workgroup_size;
     uint32_t lds_bytes;
     uint32_t scene_in_lds;    /* 1 when the whole traversal structure is LDS-resident */
+    uint32_t trace_launches;  /* launches of the path-tracing kernel (one per 64 samples per pixel) */
+    float    trace_ms;        /* sum of their hipEvent durations (the dominant kernel) */
 } rt_timing;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */
@@ -171,6 +173,8 @@ rt_status rt_render(rt_scene *scene, const rt_camera_data *cam, const rt_shard *
 
 /* Milliseconds of the most recent rt_render kernel of this scene (waits for it). */
 rt_status rt_last_kernel_ms(rt_scene *scene, float *ms);
+/* The whole rt_timing of the most recent rt_render of this scene (waits for it). */
+rt_status rt_last_timing(rt_scene *scene, rt_timing *timing);
 
 /* Convenience for hosts without their own device allocator: the whole of Camera::render up to
  * and including its cudaMemcpy D2H (src/camera.cu:198-209) into a HOST buffer. */

@@ -178,11 +178,11 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
         for (int32_t p = 0; p < count; ++p) {
             const rt_bvh_node &n = d.nodes[order[static_cast<size_t>(p)]];
             float *o = &out.tnodes[static_cast<size_t>(p) * 8];
-            o[0] = n.box[0]; o[1] = n.box[2]; o[2] = n.box[4]; o[3] = n.box[1]; o[4] = n.box[3]; o[5] = n.box[5];
+            for (int k = 0; k < 6; ++k) o[k] = n.box[k];      // x.min x.max y.min y.max z.min z.max, as the caller has them
             o[6] = bits_as_float(skip[static_cast<size_t>(p)]);
-            int32_t prim = -1;
-            if (n.left < 0 && (n.type == 0 || n.type == 1)) prim = 2 * n.right + n.type;
-            o[7] = bits_as_float(prim);
+            int32_t prim_plus_1 = 0;
+            if (n.left < 0 && (n.type == 0 || n.type == 1)) prim_plus_1 = 2 * n.right + n.type + 1;
+            o[7] = bits_as_float(prim_plus_1);
         }
     }
 

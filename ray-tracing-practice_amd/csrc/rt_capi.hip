@@ -37,6 +37,7 @@ int env_int(const char *name, int fallback) {
 
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr int kMaxPasses = 1024;        // 64 samples per pass
+constexpr int kTimedPasses = 64;        // trace launches individually timed per call
 
 // Traversal mode.  "threaded" (default): the caller's tree in the reference's own visit order —
 // results equal the reference's even where they depend on visit order.  "ordered": SAH child-pair
@@ -61,6 +62,9 @@ struct rt_scene {
     size_t slab_float4s = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> pass_events;   // pairs around each trace launch (first kTimedPasses passes)
+    int timed_passes = 0;
+    rt_timing last{};
     bool timed = false;
     int num_cus = 0;
 };
@@ -196,6 +200,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->tnodes);
     (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
+    for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
     delete sc;
@@ -263,6 +268,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         sc->slab_float4s = need;
     }
     P.slab = sc->slab;
+    P.num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
     const int passes = (P.spp + 63) / 64;
     if (passes > kMaxPasses) return fail(RT_ERR_UNSUPPORTED, "samples_per_pixel above 65536");
     const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
@@ -275,8 +281,16 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         hipLaunchKernelGGL(kernel, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
         return hipGetLastError();
     };
+    while ((int)sc->pass_events.size() < 2 * (passes < kTimedPasses ? passes : kTimedPasses)) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        sc->pass_events.push_back(e);
+    }
+    sc->timed_passes = 0;
     for (int pass = 0; pass < passes; ++pass) {
         // samples [64*pass, 64*pass + count) of every pixel, traced in any order into the slab …
+        const bool timed_pass = pass < kTimedPasses;
+        if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[2 * pass], stream));
         P.pass_first = pass * 64;
         P.pass_count = P.spp - P.pass_first < 64 ? P.spp - P.pass_first : 64;
         P.queue = sc->queue + pass;
@@ -284,6 +298,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         else if (in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>));
         else if (threaded) HIP_TRY(launch(rtk::render_kernel<false, true>));
         else HIP_TRY(launch(rtk::render_kernel<false, false>));
+        if (timed_pass) { HIP_TRY(hipEventRecord(sc->pass_events[2 * pass + 1], stream)); sc->timed_passes = pass + 1; }
         // … then added to the pixel sums strictly in sample order
         hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 255) / 256), dim3(256), 0, stream, d_fb_sum,
                            (const float4 *)sc->slab, num_pixels, P.pass_count, pass == 0 ? 1 : 0, P.slot_shift);
@@ -291,16 +306,33 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_stop, stream));
     sc->timed = true;
-    if (timing) {
-        timing->num_workgroups = (uint32_t)wgs;
-        timing->workgroup_size = rtk::kBlock;
-        timing->lds_bytes = lds_bytes;
-        timing->scene_in_lds = in_lds ? 1u : 0u;
-    }
-    if (sync) {
+    sc->last = rt_timing{};
+    sc->last.num_workgroups = (uint32_t)wgs;
+    sc->last.workgroup_size = rtk::kBlock;
+    sc->last.lds_bytes = lds_bytes;
+    sc->last.scene_in_lds = in_lds ? 1u : 0u;
+    sc->last.trace_launches = (uint32_t)passes;
+    if (sync) return rt_last_timing(sc, timing);
+    if (timing) *timing = sc->last;
+    return RT_OK;
+}
+
+rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
+    if (!sc) return fail(RT_ERR_INVALID_ARG, "null argument");
+    if (sc->timed) {
         HIP_TRY(hipEventSynchronize(sc->ev_stop));
-        if (timing) HIP_TRY(hipEventElapsedTime(&timing->kernel_ms, sc->ev_start, sc->ev_stop));
+        HIP_TRY(hipEventElapsedTime(&sc->last.kernel_ms, sc->ev_start, sc->ev_stop));
+        float sum = 0.0f;
+        for (int p = 0; p < sc->timed_passes; ++p) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[2 * p], sc->pass_events[2 * p + 1]));
+            sum += ms;
+        }
+        // passes beyond the individually timed ones are priced at the mean of the timed ones
+        if (sc->timed_passes > 0) sum *= (float)sc->last.trace_launches / (float)sc->timed_passes;
+        sc->last.trace_ms = sum;
     }
+    if (timing) *timing = sc->last;
     return RT_OK;
 }
 

@@ -60,7 +60,8 @@ class Shard(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("num_workgroups", C.c_uint32), ("workgroup_size", C.c_uint32),
-                ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32)]
+                ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("trace_launches", C.c_uint32),
+                ("trace_ms", C.c_float)]
 
 
 class ConfigInfo(C.Structure):
@@ -74,6 +75,7 @@ assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
 # Every symbol include/rtp_amd.h declares (tests check that the library exports all of them).
 RTP_AMD_SYMBOLS = [
     "rt_set_device", "rt_scene_create", "rt_scene_destroy", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
+    "rt_last_timing",
     "rt_render_to_host", "rt_trace_samples", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
     "rt_get_last_error_string", "rt_version_string",
 ]
@@ -125,6 +127,7 @@ def amd_lib():
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p, C.c_void_p,
                                   C.c_int32, C.POINTER(Timing)]
         lib.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.rt_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         lib.rt_render_to_host.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p,
                                           C.POINTER(Timing)]
         lib.rt_trace_samples.argtypes = [C.c_void_p, C.POINTER(CameraData), C.c_int32, C.c_void_p, C.c_void_p,
@@ -246,6 +249,12 @@ class DeviceScene:
         ms = C.c_float()
         _check(amd_lib().rt_last_kernel_ms(self._h, C.byref(ms)), "rt_last_kernel_ms")
         return ms.value
+
+    def last_timing(self):
+        """Full rt_timing of the most recent rt_render of this scene (waits for it)."""
+        t = Timing()
+        _check(amd_lib().rt_last_timing(self._h, C.byref(t)), "rt_last_timing")
+        return t
 
     def trace_samples(self, cam, ijs):
         ijs = np.ascontiguousarray(ijs, dtype=np.int32).reshape(-1, 3)
