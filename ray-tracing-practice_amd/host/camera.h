@@ -120,4 +120,8 @@ void orbit_pose(const SceneParams &p, int frame, Vec3 &eye, Vec3 &target);
 // "n \t ms \t W*H*sqrt_spp^2".  The scene must already be bound.
 void gpu_render(const SceneParams &params);
 
+// Animation driver beyond the reference: frames dealt round-robin to num_devices GPUs, saver
+// arithmetic on the device, file output overlapped with the next frame.  Same files, byte for byte.
+void gpu_render_pipelined(const SceneParams &params, const rt_scene_desc &desc, int num_devices);
+
 }  // namespace rtp

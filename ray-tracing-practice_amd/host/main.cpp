@@ -3,6 +3,7 @@
 // description.  --cpu is the reference's single-threaded CPU loop: this build ships no CPU
 // render path (its CPU restatement lives under oracle/ as a test checker only), so --cpu fails
 // loudly instead of silently rendering on the host.
+#include <cstdlib>
 #include <iostream>
 #include <string>
 
@@ -26,8 +27,18 @@ int main(int argc, char *argv[]) {
     rtp::HostScene host;
     rtp::build_config_scene(params, "", host);
 
-    rt_scene *scene = nullptr;
     const rt_scene_desc desc = host.desc();
+    // extension: `--gpu --devices N` (or RTP_DEVICES=N) renders the animation with the pipelined
+    // multi-GPU driver; the default is the reference's frame-after-frame loop.
+    int devices = 0;
+    if (const char *env = getenv("RTP_DEVICES")) devices = atoi(env);
+    for (int a = 2; a + 1 < argc; ++a)
+        if (std::string(argv[a]) == "--devices") devices = atoi(argv[a + 1]);
+    if (devices > 0) {
+        rtp::gpu_render_pipelined(params, desc, devices);
+        return 0;
+    }
+    rt_scene *scene = nullptr;
     RTP_CHECK(rt_scene_create(&desc, &scene));
     rtp::bind_scene(scene);
     rtp::gpu_render(params);

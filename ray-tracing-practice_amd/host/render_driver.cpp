@@ -5,7 +5,11 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "camera.h"
 #include "scene_params.h"
@@ -65,6 +69,86 @@ void gpu_render(const SceneParams &params) {
         std::cout << n << "\t" << ms << "\t" << total_rays << "\n";
     }
     rt_device_free(d_fb);  // unchecked in the reference too (src/camera.cu:348)
+}
+
+// ---- animation driver ("next" rows f1 + f2 of SURVEY.md §8) ---------------------------------------
+// The reference renders its frames one after the other on one GPU and spends most of each frame's
+// wall time pushing pixels through three 1-byte ofstream writes (src/camera.cu:211-215,148-152).
+// Frames are independent (each has its own camera pose and output file), so here
+//   * frames are dealt round-robin to `num_devices` GPUs, one host thread and one rt_scene per GPU;
+//   * the saver arithmetic runs on the device (rt_tonemap: byte-exact ISaver::writeColor), so
+//     the D2H copy is RGB8 (4x smaller than the float sums);
+//   * the file of frame n is written by a writer thread while frame n+1 renders.
+// The files are byte-identical to what gpu_render() above (and the reference) writes.
+namespace {
+
+struct PendingFile {
+    std::string path;
+    int width = 0, height = 0;
+    std::vector<uint8_t> rgb;
+};
+
+void write_binary_frame(const PendingFile &f) {
+    std::ofstream out(f.path, std::ios::binary);
+    const int32_t hdr[2] = {f.width, f.height};     // BinarySaver::setFormat (src/camera.cu:131-136)
+    out.write(reinterpret_cast<const char *>(hdr), sizeof(hdr));
+    out.write(reinterpret_cast<const char *>(f.rgb.data()), static_cast<std::streamsize>(f.rgb.size()));
+}
+
+}  // namespace
+
+void gpu_render_pipelined(const SceneParams &params, const rt_scene_desc &desc, int num_devices) {
+    if (num_devices < 1) num_devices = 1;
+    std::mutex print_mutex;
+    auto worker = [&](int dev) {
+        RTP_CHECK(rt_set_device(dev));
+        rt_scene *scene = nullptr;
+        RTP_CHECK(rt_scene_create(&desc, &scene));
+        const size_t num_pixels = static_cast<size_t>(params.width) * params.height;
+        float *d_fb = nullptr;
+        uint8_t *d_rgb = nullptr;
+        RTP_CHECK(rt_device_alloc(num_pixels * 3 * sizeof(float), reinterpret_cast<void **>(&d_fb)));
+        RTP_CHECK(rt_device_alloc(num_pixels * 3, reinterpret_cast<void **>(&d_rgb)));
+        std::thread writer;
+        for (int n = dev; n < params.num_frames; n += num_devices) {
+            char filename[256];
+            snprintf(filename, sizeof(filename), params.output_pattern.c_str(), n);
+            Vec3 eye, target;
+            orbit_pose(params, n, eye, target);
+            Camera camera(params.height, params.width, nullptr, eye, target);
+            camera.vfov = params.fov_degrees;
+            camera.samples_per_pixel = params.sqrt_spp * params.sqrt_spp;
+            camera.max_depth = params.max_depth;
+            camera.background_color = Vec3(0, 0, 0);
+            const rt_camera_data cam = camera.build_camera_data();
+
+            const auto t0 = std::chrono::steady_clock::now();
+            rt_timing timing{};
+            RTP_CHECK(rt_render(scene, &cam, nullptr, d_fb, nullptr, 1, &timing));
+            RTP_CHECK(rt_tonemap(d_fb, d_rgb, static_cast<int64_t>(num_pixels) * 3, params.sqrt_spp, nullptr));
+            auto file = std::make_shared<PendingFile>();
+            file->path = filename;
+            file->width = params.width;
+            file->height = params.height;
+            file->rgb.resize(num_pixels * 3);
+            RTP_CHECK(rt_copy_to_host(file->rgb.data(), d_rgb, num_pixels * 3));
+            if (writer.joinable()) writer.join();           // at most one file in flight per GPU
+            writer = std::thread([file]() { write_binary_frame(*file); });
+            const auto t1 = std::chrono::steady_clock::now();
+            const float ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+            const long long total_rays = static_cast<long long>(params.width) * params.height * params.sqrt_spp * params.sqrt_spp;
+            std::lock_guard<std::mutex> lock(print_mutex);
+            std::cout << n << "\t" << ms << "\t" << total_rays << "\n";
+        }
+        if (writer.joinable()) writer.join();
+        rt_device_free(d_fb);
+        rt_device_free(d_rgb);
+        RTP_CHECK(rt_scene_destroy(scene));
+    };
+    std::vector<std::thread> threads;
+    for (int d = 1; d < num_devices; ++d) threads.emplace_back(worker, d);
+    worker(0);
+    for (std::thread &t : threads) t.join();
 }
 
 }  // namespace rtp

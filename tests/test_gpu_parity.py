@@ -282,3 +282,39 @@ def test_stress_scene_bvh_from_global_memory():
     fb, t = dev.render_to_host(cam)
     assert t.scene_in_lds == 0
     assert_same_frame(fb, ob.render(host, cam, threads=8), "100k spheres")
+
+
+def test_cli_frame_drivers_write_reference_bytes(test_config_text, golden, tmp_path):
+    """rtp_main (the reference's CLI shape): frame-after-frame driver and the pipelined driver
+    (device-side saver arithmetic + overlapped file output) write the same bytes; frame 0 of the
+    unmodified test config is the file the reference's CPU path wrote (sha256 pin)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = os.path.join(root, "ray-tracing-practice_amd", "rtp_main")
+    lines = test_config_text.split("\n")
+    assert lines[0] == "1" and lines[1] == "test_output_%d.png"
+    # (a) the unmodified scene, one frame
+    lines[1] = str(tmp_path / "a_%d.png")
+    out = subprocess.run([exe, "--gpu"], input="\n".join(lines), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    n, ms, rays = out.stdout.strip().split("\t")
+    assert (n, rays) == ("0", str(200 * 100 * 4)) and float(ms) > 0
+    data = open(tmp_path / "a_0.png", "rb").read()
+    assert hashlib.sha256(data).hexdigest() == golden["test_config_binary_saver_sha256"]
+    # (b) a 3-frame orbit, both drivers
+    lines[0] = "3"
+    lines[5] = "0.0 0.0 1.0"          # wrc wzc wc: the eye circles the scene
+    for tag, extra in (("seq", []), ("pipe", ["--devices", "1"])):
+        lines[1] = str(tmp_path / (tag + "_%d.png"))
+        out = subprocess.run([exe, "--gpu"] + extra, input="\n".join(lines), capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert len(out.stdout.strip().split("\n")) == 3
+    host = rb.HostScene.from_config("\n".join(lines))
+    for f in range(3):
+        a = open(tmp_path / f"seq_{f}.png", "rb").read()
+        b = open(tmp_path / f"pipe_{f}.png", "rb").read()
+        assert a == b and len(a) == 60008
+        cam = host.frame_camera(f)
+        want = rb.binary_image_bytes(ob.render(host, cam, threads=4), 200, 100, host.info.sqrt_spp)
+        assert a == want
+    assert open(tmp_path / "seq_0.png", "rb").read() != open(tmp_path / "seq_1.png", "rb").read()
