@@ -12,6 +12,7 @@
 #include "rt_accel.h"
 #include "rt_device_math.h"
 #include "rt_kernel.hip.inc"
+#include "rt_kernel_queue.hip.inc"
 
 namespace {
 
@@ -287,6 +288,39 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         sc->pass_events.push_back(e);
     }
     sc->timed_passes = 0;
+    // RTP_KERNEL=queue: T-waves/S-waves with LDS queues (rt_kernel_queue.hip.inc), threaded + LDS-resident scenes only
+    bool use_queue = false;
+    uint32_t q_lds = 0;
+    if (const char *kq = getenv("RTP_KERNEL")) use_queue = std::string(kq) == "queue";
+    if (use_queue && threaded && in_lds) {
+        P.q_s_waves = env_int("RTP_Q_SWAVES", 4);
+        P.q_k_refill = env_int("RTP_Q_KREFILL", 16);
+        P.q_k_busy = env_int("RTP_Q_KBUSY", 0);
+        P.q_k_leaf = env_int("RTP_Q_KLEAF", 24);
+        const uint64_t base_f4 = node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + ((uint64_t)P.num_spheres + 3) / 4;
+        const uint64_t mat_bytes = (uint64_t)P.num_materials * 48;
+        uint32_t slots = (uint32_t)env_int("RTP_Q_SLOTS", 1152);
+        auto lds_for = [&](uint32_t n, bool mats) {
+            uint32_t cap = 64;
+            while (cap < n) cap <<= 1;
+            return base_f4 * 16 + (mats ? mat_bytes : 0) + (uint64_t)n * rtk::kSlotDwords * 4 + 2ull * cap * 4 + (rtk::QC_WORDS + 2 * (rtk::kQBlock / rtk::kWave)) * 4 + 16;
+        };
+        P.q_mats_in_lds = env_int("RTP_Q_MATS_LDS", 1);
+        if (P.q_mats_in_lds && lds_for(slots, true) > kLdsLimit) P.q_mats_in_lds = 0;
+        while (slots > 128 && lds_for(slots, P.q_mats_in_lds != 0) > kLdsLimit) slots -= 64;
+        if (lds_for(slots, P.q_mats_in_lds != 0) > kLdsLimit) use_queue = false;
+        P.q_slots = slots;
+        P.q_ring_cap = 64;
+        while (P.q_ring_cap < slots) P.q_ring_cap <<= 1;
+        q_lds = (uint32_t)lds_for(slots, P.q_mats_in_lds != 0);
+    } else {
+        use_queue = false;
+    }
+    if (use_queue) {
+        wgs = sc->num_cus;
+        if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
+        if (wgs < 1) wgs = 1;
+    }
     for (int pass = 0; pass < passes; ++pass) {
         // samples [64*pass, 64*pass + count) of every pixel, traced in any order into the slab …
         const bool timed_pass = pass < kTimedPasses;
@@ -294,7 +328,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         P.pass_first = pass * 64;
         P.pass_count = P.spp - P.pass_first < 64 ? P.spp - P.pass_first : 64;
         P.queue = sc->queue + pass;
-        if (in_lds && threaded) HIP_TRY(launch(rtk::render_kernel<true, true>));
+        if (use_queue) {
+            HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel_q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds));
+            hipLaunchKernelGGL(rtk::render_kernel_q<true>, dim3(wgs), dim3(rtk::kQBlock), q_lds, stream, P);
+            HIP_TRY(hipGetLastError());
+        } else if (in_lds && threaded) HIP_TRY(launch(rtk::render_kernel<true, true>));
         else if (in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>));
         else if (threaded) HIP_TRY(launch(rtk::render_kernel<false, true>));
         else HIP_TRY(launch(rtk::render_kernel<false, false>));
@@ -308,8 +346,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->timed = true;
     sc->last = rt_timing{};
     sc->last.num_workgroups = (uint32_t)wgs;
-    sc->last.workgroup_size = rtk::kBlock;
-    sc->last.lds_bytes = lds_bytes;
+    sc->last.workgroup_size = use_queue ? rtk::kQBlock : rtk::kBlock;
+    sc->last.lds_bytes = use_queue ? q_lds : lds_bytes;
     sc->last.scene_in_lds = in_lds ? 1u : 0u;
     sc->last.trace_launches = (uint32_t)passes;
     if (sync) return rt_last_timing(sc, timing);
@@ -331,6 +369,9 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
         // passes beyond the individually timed ones are priced at the mean of the timed ones
         if (sc->timed_passes > 0) sum *= (float)sc->last.trace_launches / (float)sc->timed_passes;
         sc->last.trace_ms = sum;
+        uint32_t abort_code = 0;
+        HIP_TRY(hipMemcpy(&abort_code, sc->queue + kMaxPasses + 15, 4, hipMemcpyDeviceToHost));
+        if (abort_code != 0) return fail(RT_ERR_HIP, "render_kernel_q aborted (queue protocol timeout, code " + std::to_string(abort_code) + ")");
     }
     if (timing) *timing = sc->last;
     return RT_OK;

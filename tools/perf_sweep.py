@@ -22,3 +22,9 @@ if os.environ.get('STATS'):
         it,ln=out[2*k],out[2*k+1]
         print('  %-10s kticks %9d'%(n,out[8+k]) if k<4 else '', end=' ')
         print(' wave-steps %10d  full-wave-equiv %10d  util %.3f  per-sample lane-steps %.2f'%(it,ln,ln/max(it,1), ln*64/ns))
+
+if os.environ.get('QSTATS'):
+    out=(C.c_uint32*12)()
+    lib.rt_debug_read_stats(ds._h, out)
+    print('  T: iters %d exchanges %d popped %d idle %d boxvotes %d boxlanes/64 %d'%tuple(out[0:6]))
+    print('  S: batches %d - popped %d idle %d'%(out[6],out[8],out[9]))
