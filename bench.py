@@ -90,8 +90,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        except TypeError:       # older torch: no device_id keyword
+            dist.init_process_group("nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)

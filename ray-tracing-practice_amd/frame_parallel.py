@@ -14,6 +14,7 @@ import torch.distributed as dist
 import rtp_bindings as rb
 
 DEFAULT_BAND_ROWS = 8
+_USE_ALL_GATHER = False
 
 
 def shard_for_rank(rank, world_size, band_rows=DEFAULT_BAND_ROWS):
@@ -42,13 +43,27 @@ def gather_frame(local_fb, height, band_rows, group=None, dst=0):
         send = torch.zeros((pad_rows, width, 3), dtype=local_fb.dtype, device=local_fb.device)
         send[:local_fb.shape[0]] = local_fb
     send = send.contiguous()
-    if rank == dst:
+    global _USE_ALL_GATHER
+    parts = None
+    if not _USE_ALL_GATHER:
+        try:
+            if rank == dst:
+                parts = [torch.empty_like(send) for _ in range(world)]
+                dist.gather(send, parts, dst=dst, group=group)
+            else:
+                dist.gather(send, None, dst=dst, group=group)
+        except (RuntimeError, NotImplementedError):
+            # a backend without gather: every rank takes this branch on the same call (the error is
+            # raised before any communication), then all of them use all_gather from here on
+            _USE_ALL_GATHER = True
+            parts = None
+    if _USE_ALL_GATHER:
         parts = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, parts, dst=dst, group=group)
-        frame = torch.empty((height, width, 3), dtype=local_fb.dtype, device=local_fb.device)
-        for r in range(world):
-            idx = torch.as_tensor(shard_row_indices(height, band_rows, world, r), device=local_fb.device)
-            frame.index_copy_(0, idx, parts[r][:counts[r]])
-        return frame
-    dist.gather(send, None, dst=dst, group=group)
-    return None
+        dist.all_gather(parts, send, group=group)
+    if rank != dst:
+        return None
+    frame = torch.empty((height, width, 3), dtype=local_fb.dtype, device=local_fb.device)
+    for r in range(world):
+        idx = torch.as_tensor(shard_row_indices(height, band_rows, world, r), device=local_fb.device)
+        frame.index_copy_(0, idx, parts[r][:counts[r]])
+    return frame

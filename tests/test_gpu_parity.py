@@ -318,3 +318,38 @@ def test_cli_frame_drivers_write_reference_bytes(test_config_text, golden, tmp_p
         want = rb.binary_image_bytes(ob.render(host, cam, threads=4), 200, 100, host.info.sqrt_spp)
         assert a == want
     assert open(tmp_path / "seq_0.png", "rb").read() != open(tmp_path / "seq_1.png", "rb").read()
+
+
+def test_alternative_kernels_agree_with_default(rtiow):
+    """RTP_KERNEL=queue (T/S waves + LDS queues) must be bit-identical to the default kernel;
+    RTP_TRAVERSAL=ordered (near-first SAH walk) is allowed the order-dependent rays DESIGN.md §3
+    describes — tolerance: at least 99.99 % of the pixels bit-identical."""
+    host, dev = rtiow
+    cam = rb.rtiow_camera(320, 200, 8, 50)
+    want, _ = dev.render_to_host(cam)
+    assert_same_frame(want, ob.render(host, cam, threads=8), "default kernel")
+    try:
+        os.environ["RTP_KERNEL"] = "queue"
+        got, t = dev.render_to_host(cam)
+        assert t.workgroup_size == 1024
+        assert_same_frame(got, want, "queue kernel")
+        del os.environ["RTP_KERNEL"]
+        os.environ["RTP_TRAVERSAL"] = "ordered"
+        got, _ = dev.render_to_host(cam)
+        same = (bits(got) == bits(want)).all(axis=-1)
+        assert same.mean() >= 0.9999, f"{(~same).sum()} pixels differ"
+    finally:
+        os.environ.pop("RTP_KERNEL", None)
+        os.environ.pop("RTP_TRAVERSAL", None)
+
+
+def test_stress_scene_at_4k_rows():
+    """BASELINE configs[4] geometry: ~100k spheres + a textured quad at 3840x2160 (2 spp here);
+    index arithmetic at full size (8.3 M pixels, 531 M work indices) and rows against the oracle."""
+    host = rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=256)
+    dev = rb.DeviceScene(host, device=0)
+    cam = rb.rtiow_camera(3840, 2160, 2, 50)
+    fb, t = dev.render_to_host(cam)
+    assert t.scene_in_lds == 0
+    for row in (5, 1080, 2100):
+        assert_same_frame(fb[row:row + 1], ob.render(host, cam, row0=row, row1=row + 1, threads=8), f"4K row {row}")
