@@ -174,15 +174,23 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
             else skip[static_cast<size_t>(p)] = skip[static_cast<size_t>(pos_of[static_cast<size_t>(n.right)])];
         }
         out.num_tnodes = count;
-        out.tnodes.resize(static_cast<size_t>(count) * 8);
+        out.tnodes.resize(static_cast<size_t>(count + 1) * 8);
+        const int32_t blocked = INT32_MIN;      // sign bit: "no box test wanted" (see step_threaded)
         for (int32_t p = 0; p < count; ++p) {
             const rt_bvh_node &n = d.nodes[order[static_cast<size_t>(p)]];
             float *o = &out.tnodes[static_cast<size_t>(p) * 8];
             for (int k = 0; k < 6; ++k) o[k] = n.box[k];      // x.min x.max y.min y.max z.min z.max, as the caller has them
-            o[6] = bits_as_float(skip[static_cast<size_t>(p)]);
-            int32_t prim_plus_1 = 0;
-            if (n.left < 0 && (n.type == 0 || n.type == 1)) prim_plus_1 = 2 * n.right + n.type + 1;
-            o[7] = bits_as_float(prim_plus_1);
+            const int32_t miss = skip[static_cast<size_t>(p)];
+            o[6] = bits_as_float(miss == count ? (count | blocked) : miss);     // the link that ends the walk is negative
+            int32_t leaf = 0;
+            if (n.left < 0 && (n.type == 0 || n.type == 1)) leaf = (2 * n.right + n.type + 1) | blocked;
+            o[7] = bits_as_float(leaf);
+        }
+        {   // end sentinel at index count: reached when the last node's box was hit; never hit itself
+            float *o = &out.tnodes[static_cast<size_t>(count) * 8];
+            o[0] = 1e30f; o[1] = -1e30f; o[2] = 1e30f; o[3] = -1e30f; o[4] = 1e30f; o[5] = -1e30f;
+            o[6] = bits_as_float(count | blocked);
+            o[7] = bits_as_float(0);
         }
     }
 

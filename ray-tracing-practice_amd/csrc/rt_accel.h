@@ -33,9 +33,10 @@ struct Packed {
     std::vector<int32_t> tex_info; // 4 per texture: float offset (in float4 units), width, height, 0
     // "Threaded" copy of the caller's tree for reference-order traversal: 8 floats per node, nodes
     // in the order hit_bvh pops them (left child first, include/bvh.h:52-59): x.min x.max y.min
-    // y.max | z.min z.max, skip (index of the next node when this subtree is skipped), prim + 1
-    // (2*index+type+1 for a typed leaf, 0 otherwise).  Visiting node k: box hit → next is k+1,
-    // miss → next is skip; index num_tnodes = done.
+    // y.max | z.min z.max, miss link (index of the next node when this subtree is skipped; negative
+    // when that ends the walk), leaf word ((2*index+type+1) | sign bit for a typed leaf, 0
+    // otherwise).  Visiting node k: box hit → next is k+1, miss → miss link.  One extra record at
+    // index num_tnodes is an end sentinel whose box is never hit.
     std::vector<float> tnodes;
     int32_t num_tnodes = 0;
     int32_t root = kTraversalDone; // node code of the root (leaf code when the scene has one primitive)

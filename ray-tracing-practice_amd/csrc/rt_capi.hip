@@ -120,7 +120,6 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.sphere_mat = sc->sphere_mat;
     P.tex_data = sc->tex_data; P.tex_info = sc->tex_info;
     P.queue = sc->queue;
-    P.tiles_x = 0;
     if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "more than 2^25 pixels per call");
     P.slot_shift = 6;
     while (P.slot_shift > 0 && (1 << (P.slot_shift - 1)) >= P.spp) P.slot_shift--;     // next power of two >= spp, at most 64
@@ -129,13 +128,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.stack_levels = sc->tree_depth + 1;
     if (P.stack_levels < 2) P.stack_levels = 2;
     P.k_inner = env_int("RTP_K_INNER", 24);
-    P.k_shade = env_int("RTP_K_SHADE", 40);
-    {   // ~1024 samples per reserved range: 64 pixels at 16 spp, exact-need at >= 1024 spp
-        int refill = P.spp > 0 ? 1024 / P.spp : 64;
-        if (refill > 64) refill = 64;
-        if (refill < 1) refill = 1;
-        P.pool_refill = (uint32_t)env_int("RTP_POOL_REFILL", refill);
-    }
+    P.k_shade = env_int("RTP_K_SHADE", 48);
     return RT_OK;
 }
 
@@ -243,7 +236,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     const uint32_t waves = rtk::kBlock / rtk::kWave;
     if (threaded) P.stack_levels = 0;
     const uint32_t stack_bytes = waves * (uint32_t)P.stack_levels * rtk::kWave * 4u + waves * 8u;   // + per-wave pixel ranges
-    const uint64_t node_f4 = threaded ? (uint64_t)P.num_tnodes * 2 : (uint64_t)P.num_internal * 4;
+    const uint64_t node_f4 = threaded ? ((uint64_t)P.num_tnodes + 1) * 2 : (uint64_t)P.num_internal * 4;
     const uint64_t scene_bytes = (node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
                                   ((uint64_t)P.num_spheres + 3) / 4) * 16;
     // two workgroups per CU when both fit in LDS, else one, else tables stay in global memory
