@@ -1,5 +1,6 @@
 #include "rtp_host.h"
 
+#include <algorithm>
 #include <sstream>
 #include <string>
 
@@ -91,6 +92,22 @@ int32_t rtp_host_write_png(const char *path, const float *fb_sum, int32_t width,
     saver.set_format(width, height);
     for (int64_t p = 0; p < static_cast<int64_t>(width) * height; ++p)
         saver.write_color(rtp::Vec3(fb_sum[3 * p], fb_sum[3 * p + 1], fb_sum[3 * p + 2]));
+    return 0;
+}
+
+int32_t rtp_host_load_texture(const char *path, int32_t *width, int32_t *height, float *rgba) {
+    static thread_local std::string cached_path;
+    static thread_local rtp::TextureImage cached;
+    if (!path || !width || !height) return 1;
+    if (cached_path != path) {
+        rtp::TextureImage img;
+        if (!rtp::load_texture(path, img)) return 1;
+        cached = std::move(img);
+        cached_path = path;
+    }
+    *width = cached.width;
+    *height = cached.height;
+    if (rgba) std::copy(cached.rgba.begin(), cached.rgba.end(), rgba);
     return 0;
 }
 

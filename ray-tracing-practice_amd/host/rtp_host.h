@@ -44,6 +44,9 @@ void rtp_host_quantize(const float *fb_sum, int64_t num_pixels, int32_t divisor,
 /* BinarySaver file image: 8-byte header + RGB8.  Returns 0 on success. */
 int32_t rtp_host_write_binary_image(const char *path, const float *fb_sum, int32_t width, int32_t height, int32_t divisor);
 int32_t rtp_host_write_png(const char *path, const float *fb_sum, int32_t width, int32_t height, int32_t divisor);
+/* Host texture loader (JPEG / PPM / PFM → float RGBA, stbi_loadf rule).  Returns 0 on success and
+ * fills width/height; rgba (may be NULL to query the size) receives width*height*4 floats. */
+int32_t rtp_host_load_texture(const char *path, int32_t *width, int32_t *height, float *rgba);
 /* Text of `main --default`. */
 const char *rtp_host_default_config(void);
 

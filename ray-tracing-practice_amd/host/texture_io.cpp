@@ -1,5 +1,7 @@
 #include "texture_io.h"
 
+#include "jpeg_decoder.h"
+
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -34,6 +36,21 @@ bool read_token(std::istream &in, std::string &tok) {
 }  // namespace
 
 bool load_texture(const std::string &path, TextureImage &out) {
+    {   // JPEG (SOI marker FF D8): the reference's floor textures are JPEGs
+        std::ifstream probe(path, std::ios::binary);
+        unsigned char magic[2] = {0, 0};
+        probe.read(reinterpret_cast<char *>(magic), 2);
+        if (probe.gcount() == 2 && magic[0] == 0xFF && magic[1] == 0xD8) {
+            int w = 0, h = 0;
+            std::vector<uint8_t> rgb;
+            if (!decode_jpeg_rgb8(path, w, h, rgb)) {
+                std::cerr << "Failed to load texture: " << path << std::endl;
+                return false;
+            }
+            ldr_to_linear_rgba(rgb.data(), w, h, 3, out);
+            return true;
+        }
+    }
     std::ifstream in(path, std::ios::binary);
     std::string magic, tw, th, tmax;
     if (!in || !read_token(in, magic) || (magic != "P6" && magic != "PF") || !read_token(in, tw) ||

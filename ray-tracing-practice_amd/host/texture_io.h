@@ -4,9 +4,10 @@
 // The reference decodes with the vendored stb_image (stbi_loadf(...,4), src/main.cu:52-60), which
 // converts 8-bit channels to linear floats as pow(c/255, 2.2) and alpha as a/255
 // (stb_image.h:1858-1884).  stb_image is third-party code that is not part of this repository;
-// this loader reads binary PPM (P6, 8-bit) and PFM (PF) files and applies the same 8-bit→float
-// rule.  Anything else fails exactly like a failed stbi_loadf: message on stderr, untextured
-// material (src/main.cu:55-58).
+// this loader reads baseline JPEG (own decoder, jpeg_decoder.cpp, checked byte for byte against
+// the reference's decoder on the reference's floor.jpg), binary PPM (P6, 8-bit) and PFM (PF) files
+// and applies the same 8-bit→float rule.  Anything else fails exactly like a failed stbi_loadf:
+// message on stderr, untextured material (src/main.cu:55-58).
 #pragma once
 #include <string>
 #include <vector>

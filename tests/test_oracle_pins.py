@@ -74,33 +74,56 @@ def test_reference_image_sha256(test_config_text, golden):
 
 def test_textured_reference_image_sha256(golden, tmp_path):
     """Second full-image pin: the reference's config.txt shrunk to 400x225, depth
-    10, 4^2 spp with floor.jpg as the floor texture.  Covers tex2D_cpu, the textured METAL floor
-    and the polyhedra at a second resolution.  floor.jpg is decoded by the reference's OWN vendored
-    stb_image.h, compiled where it lies by oracle/Makefile target `_ref`; this needs /root/reference,
-    so the test runs in the build container only."""
+    10, 4^2 spp with floor.jpg as the floor texture.  Covers the host JPEG decoder, tex2D_cpu, the
+    textured METAL floor and the polyhedra at a second resolution.  Needs /root/reference (for
+    floor.jpg and config.txt), so it runs in the build container only."""
     import os
-    import subprocess
     import pytest
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ref = "/root/reference"
     if not os.path.exists(os.path.join(ref, "floor.jpg")):
         pytest.skip("reference tree not present (GPU box)")
-    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "_ref"], check=True, capture_output=True)
-    pfm = str(tmp_path / "floor.pfm")
-    subprocess.run([os.path.join(root, "oracle", "_ref", "stb_decode"), os.path.join(ref, "floor.jpg"), pfm], check=True)
     lines = open(os.path.join(ref, "config.txt")).read().split("\n")
     while not lines[-1].strip():
         lines.pop()
     lines[0] = "1"
     lines[2] = "400 225 50"
-    lines[8] = lines[8].replace("../floor2.jpg", pfm)
+    lines[8] = lines[8].replace("../floor2.jpg", os.path.join(ref, "floor.jpg"))
     lines[-1] = "10 4"
-    hs = rb.HostScene.from_config("\n".join(lines) + "\n")
+    hs = rb.HostScene.from_config("\n".join(lines) + "\n")       # the host mirror's own JPEG decoder
     assert hs.desc.num_textures == 1 and hs.desc.textures[0].width == 2000 and hs.desc.textures[0].height == 1330
     cam = hs.frame_camera(0)
     fb = ob.render(hs, cam, threads=8)
     data = rb.binary_image_bytes(fb, 400, 225, hs.info.sqrt_spp)
     assert hashlib.sha256(data).hexdigest() == golden["config_txt_400x225_d10_spp16_floor_jpg_sha256"]
+
+
+def test_jpeg_decoder_matches_reference_decoder(tmp_path):
+    """Every texel of floor.jpg decoded by host/jpeg_decoder.cpp equals, bit for bit, what the
+    reference's own vendored stb_image.h produces (compiled where it lies by `make -C oracle _ref`;
+    build container only)."""
+    import ctypes as C
+    import os
+    import subprocess
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jpg = "/root/reference/floor.jpg"
+    if not os.path.exists(jpg):
+        pytest.skip("reference tree not present (GPU box)")
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "_ref"], check=True, capture_output=True)
+    pfm = str(tmp_path / "floor.pfm")
+    subprocess.run([os.path.join(root, "oracle", "_ref", "stb_decode"), jpg, pfm], check=True)
+    lib = rb.host_lib()
+    lib.rtp_host_load_texture.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
+    w, h = C.c_int32(), C.c_int32()
+    assert lib.rtp_host_load_texture(jpg.encode(), C.byref(w), C.byref(h), None) == 0
+    mine = np.empty((h.value, w.value, 4), dtype=np.float32)
+    assert lib.rtp_host_load_texture(jpg.encode(), C.byref(w), C.byref(h), mine.ctypes.data) == 0
+    raw = open(pfm, "rb").read()
+    start = raw.index(b"-1.0\n") + 5
+    ref = np.frombuffer(raw[start:], dtype="<f4").reshape(h.value, w.value, 3)[::-1]
+    assert (w.value, h.value) == (2000, 1330)
+    assert np.array_equal(mine[:, :, :3].view(np.uint32), np.ascontiguousarray(ref).view(np.uint32))
+    assert (mine[:, :, 3] == 1.0).all()
 
 
 def test_threaded_render_equals_serial(test_config_text):

@@ -1,0 +1,19 @@
+"""BASELINE configs[4]: ~100k spheres + textured quad, 3840x2160, 1000 spp, depth 50 — one frame."""
+import os, sys, time
+sys.path.insert(0,'tests'); sys.path.insert(0,'ray-tracing-practice_amd')
+import rtp_bindings as rb, numpy as np, oracle_bindings as ob
+import torch
+spp=int(os.environ.get('SPP',1000))
+hs=rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=2048)
+cam=rb.rtiow_camera(3840,2160,spp,50)
+ds=rb.DeviceScene(hs,device=0)
+fb=torch.zeros((2160,3840,3),dtype=torch.float32,device='cuda:0')
+t0=time.time(); tm=ds.render(cam, fb.data_ptr()); dt=time.time()-t0
+ns=3840*2160*spp
+print('C5 frame: kernel_ms %.1f trace_ms %.1f launches %d  Msamples/s %.1f (wall %.1fs) lds %d in_lds %d'%(tm.kernel_ms,tm.trace_ms,tm.trace_launches,ns/tm.kernel_ms/1e3,dt,tm.lds_bytes,tm.scene_in_lds))
+got=fb.cpu().numpy()
+row=1500
+if spp<=16:
+    want=ob.render(hs,cam,row0=row,row1=row+1,threads=16)
+    print('row check identical:', np.array_equal(want.view(np.uint32), got[row:row+1].view(np.uint32)))
+print('mean radiance', got.mean()/spp)
