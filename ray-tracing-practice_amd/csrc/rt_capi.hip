@@ -121,9 +121,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.tex_data = sc->tex_data; P.tex_info = sc->tex_info;
     P.queue = sc->queue;
     if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "more than 2^25 pixels per call");
-    P.slot_shift = 6;
-    while (P.slot_shift > 0 && (1 << (P.slot_shift - 1)) >= P.spp) P.slot_shift--;     // next power of two >= spp, at most 64
-    P.total_work = ((uint32_t)P.local_rows * (uint32_t)P.width) << P.slot_shift;
+    P.total_work = (uint32_t)P.local_rows * (uint32_t)P.width * 64u;      // upper bound; set per pass in rt_render
     P.stats = sc->queue + kMaxPasses;
     P.stack_levels = sc->tree_depth + 1;
     if (P.stack_levels < 2) P.stack_levels = 2;
@@ -252,7 +250,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     if (wgs < 1) wgs = 1;
 
     // workspace: one float4 per (local pixel, slot)
-    const size_t need = (size_t)P.total_work;
+    const size_t need = (size_t)P.local_rows * (size_t)P.width * (size_t)(P.spp < 64 ? P.spp : 64);
     if (sc->slab_float4s < need) {
         HIP_TRY(hipStreamSynchronize(stream));
         (void)hipFree(sc->slab);
@@ -315,11 +313,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (wgs < 1) wgs = 1;
     }
     for (int pass = 0; pass < passes; ++pass) {
-        // samples [64*pass, 64*pass + count) of every pixel, traced in any order into the slab …
+        // samples [pass_first, pass_first + pass_count) of every pixel, traced in any order into the slab …
         const bool timed_pass = pass < kTimedPasses;
         if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[2 * pass], stream));
         P.pass_first = pass * 64;
         P.pass_count = P.spp - P.pass_first < 64 ? P.spp - P.pass_first : 64;
+        P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
         P.queue = sc->queue + pass;
         if (use_queue) {
             HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel_q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds));
@@ -332,7 +331,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (timed_pass) { HIP_TRY(hipEventRecord(sc->pass_events[2 * pass + 1], stream)); sc->timed_passes = pass + 1; }
         // … then added to the pixel sums strictly in sample order
         hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 255) / 256), dim3(256), 0, stream, d_fb_sum,
-                           (const float4 *)sc->slab, num_pixels, P.pass_count, pass == 0 ? 1 : 0, P.slot_shift);
+                           (const float4 *)sc->slab, num_pixels, P.pass_count, pass == 0 ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_stop, stream));
