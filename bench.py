@@ -44,10 +44,12 @@ def host_threads():
     return max(1, min(16, n))
 
 
-def cpu_baseline(host, threads, budget_s=12.0):
+def cpu_baseline(host, threads, budget_s=12.0, frame=None, gpu_cam=None):
     """The oracle (CPU restatement of the reference's render_cpu) on this box's host cores, on a
     bounded sample of the same workload: full 1920x1080 frame geometry, depth 50, reduced spp.
-    Also returns the traversal statistics that price the algorithmic bytes per sample."""
+    Also returns the traversal statistics that price the algorithmic bytes per sample and, since
+    the CPU path is running anyway, renders two rows at the timed configuration's full spp and
+    compares them bit for bit with the GPU frame that was just timed."""
     import oracle_bindings as ob   # the checker; never on the product path
     # single thread (what the reference's own CPU path uses): a 1080/40-row slice at 1 spp
     cam1 = rb.rtiow_camera(WIDTH, HEIGHT, 1, DEPTH)
@@ -67,12 +69,19 @@ def cpu_baseline(host, threads, budget_s=12.0):
     _, st = ob.render(host, cam, threads=threads, want_stats=True)
     dt = time.perf_counter() - t0
     multi = WIDTH * HEIGHT * spp / dt / 1e6
+    checked = None
+    if frame is not None and gpu_cam is not None:
+        rows = [HEIGHT // 3, HEIGHT - 7]
+        checked = {"rows": rows, "gpu_frame_bit_identical": bool(all(
+            np.array_equal(ob.render(host, gpu_cam, row0=r, row1=r + 1, threads=threads).view(np.uint32),
+                           frame[r:r + 1].view(np.uint32)) for r in rows))}
     return {
         "value": round(multi, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
         "sample": f"oracle render_cpu restatement, full {WIDTH}x{HEIGHT} frame, depth {DEPTH}, {spp} spp "
                   f"({WIDTH * HEIGHT * spp} samples, {dt:.1f} s, {threads} threads); single thread on "
                   f"{n1} samples of the same frame",
         "single_thread_value": round(single, 4),
+        "checked_rows": checked,
     }, st
 
 
@@ -155,19 +164,9 @@ def main():
                        "parallelism": f"row-band shard x{world} + 1 gather" if world > 1 else "single GPU",
                        "traversal": os.environ.get("RTP_TRAVERSAL", "threaded")},
         }
-        # parity spot check of the timed output: two full-width rows at full spp against the oracle
-        try:
-            import oracle_bindings as ob
-            got = frame.detach().cpu().numpy()
-            rows = [HEIGHT // 3, HEIGHT - 7]
-            same = all(np.array_equal(ob.render(host, cam, row0=r, row1=r + 1, threads=host_threads()).view(np.uint32),
-                                      got[r:r + 1].view(np.uint32)) for r in rows)
-            out["parity_check"] = {"rows": rows, "bit_identical_to_oracle": bool(same)}
-        except Exception as e:  # the checker is optional for the measurement itself
-            out["parity_check"] = {"error": str(e)}
         base, st = (None, None)
         if world == 1 and not args.no_cpu_baseline:
-            base, st = cpu_baseline(host, host_threads())
+            base, st = cpu_baseline(host, host_threads(), frame=frame.detach().cpu().numpy(), gpu_cam=cam)
             out["cpu_baseline"] = base
         # roofline of the dominant (only) kernel: algorithmic bytes per launch / mean launch time
         bytes_per_sample = st.bytes_per_sample(args.spp) if st is not None else 5790.0   # SURVEY.md §8(d) if not re-counted
