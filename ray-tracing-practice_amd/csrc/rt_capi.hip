@@ -81,6 +81,20 @@ rt_status upload(const std::vector<T> &host, void **dev) {
     return RT_OK;
 }
 
+// Reciprocal for div_magic(): exact quotients for every n <= n_max (checked, not assumed).
+bool make_magic(uint32_t d, uint64_t n_max, rtk::Magic &g) {
+    if (d == 0) return false;
+    if (d == 1) { g.m = 0; g.s = 0; return true; }
+    uint32_t lg = 0;
+    while ((2u << lg) <= d) ++lg;                     // floor(log2 d)
+    g.s = 31 + lg;
+    const uint64_t mm = ((uint64_t)1 << g.s) / d + 1;
+    if (mm >> 32) return false;
+    g.m = (uint32_t)mm;
+    // n*m/2^s - n/d = n * (m*d - 2^s) / (d * 2^s) <= n * d / (d * 2^s): the floor is exact while n * d < 2^s
+    return n_max * (uint64_t)d < ((uint64_t)1 << g.s);
+}
+
 void normalise_shard(const rt_shard *in, int32_t height, rt_shard &out) {
     if (!in || in->num_parts <= 1 || in->band_rows <= 0) {
         out.band_rows = height > 0 ? height : 1;
@@ -120,10 +134,16 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.sphere_mat = sc->sphere_mat;
     P.tex_data = sc->tex_data; P.tex_info = sc->tex_info;
     P.queue = sc->queue;
-    if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 25)) return fail(RT_ERR_UNSUPPORTED, "more than 2^25 pixels per call");
+    if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 pixels per call");
     P.total_work = (uint32_t)P.local_rows * (uint32_t)P.width * 64u;      // upper bound; set per pass in rt_render
     P.stats = sc->queue + kMaxPasses;
-    P.stack_levels = sc->tree_depth + 1;
+    {
+        const uint64_t pixels = (uint64_t)P.local_rows * (uint64_t)P.width;
+        if (!make_magic((uint32_t)P.width, pixels + 1, P.magic_width) ||
+            !make_magic((uint32_t)P.band_rows, (uint64_t)P.local_rows + 1, P.magic_band))
+            return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");
+    }
+    P.stack_levels = sc->tree_depth + 1;      // ordered traversal: one LDS stack entry per tree level at most
     if (P.stack_levels < 2) P.stack_levels = 2;
     P.k_inner = env_int("RTP_K_INNER", 24);
     P.k_shade = env_int("RTP_K_SHADE", 48);
@@ -319,6 +339,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         P.pass_first = pass * 64;
         P.pass_count = P.spp - P.pass_first < 64 ? P.spp - P.pass_first : 64;
         P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
+        if (!make_magic((uint32_t)P.pass_count, (uint64_t)P.total_work + 64, P.magic_count))
+            return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");
         P.queue = sc->queue + pass;
         if (use_queue) {
             HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel_q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds));

@@ -24,6 +24,11 @@ def _have_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    # a GPU test that hangs must not hold the box until the outer limit: hard per-test limit
+    # (thread method: the process is ended even while it sits inside a HIP call)
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(pytest.mark.timeout(240, method="thread"))
     if _have_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this environment")
