@@ -6,6 +6,7 @@
 
 #include "camera.h"
 #include "png_writer.h"
+#include "bvh_builder.h"
 #include "scene_builder.h"
 #include "scene_params.h"
 
@@ -35,6 +36,23 @@ rtp_host_scene *rtp_host_scene_rtiow(uint32_t seed, int32_t half_extent, int32_t
     o.textured_floor_quad = textured_quad != 0;
     o.texture_size = texture_size > 0 ? texture_size : 1024;
     rtp::build_rtiow_scene(o, s->scene);
+    return s;
+}
+
+rtp_host_scene *rtp_host_scene_from_arrays(const float *spheres, int32_t num_spheres, const float *planes, int32_t num_planes,
+                                           const rt_material *materials, int32_t num_materials) {
+    auto *s = new rtp_host_scene;
+    for (int32_t i = 0; i < num_spheres; ++i) {
+        const float *p = spheres + 5 * i;
+        s->scene.spheres.push_back(rtp::make_sphere(rtp::Vec3(p[0], p[1], p[2]), p[3], static_cast<int>(p[4])));
+    }
+    for (int32_t i = 0; i < num_planes; ++i) {
+        const float *p = planes + 11 * i;
+        s->scene.planes.push_back(rtp::make_plane(rtp::Vec3(p[0], p[1], p[2]), rtp::Vec3(p[3], p[4], p[5]), rtp::Vec3(p[6], p[7], p[8]),
+                                                  static_cast<int>(p[9]), static_cast<int>(p[10])));
+    }
+    s->scene.materials.assign(materials, materials + num_materials);
+    s->scene.nodes = rtp::build_bvh(s->scene.spheres, s->scene.planes);
     return s;
 }
 

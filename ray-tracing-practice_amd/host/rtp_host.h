@@ -27,6 +27,11 @@ typedef struct rtp_config_info {
 rtp_host_scene *rtp_host_scene_from_config(const char *config_text, const char *texture_dir);
 /* Benchmark scenes: half_extent 11 → S-rtiow (486 spheres); 158 → S-100k. */
 rtp_host_scene *rtp_host_scene_rtiow(uint32_t seed, int32_t half_extent, int32_t textured_quad, int32_t texture_size);
+/* A scene from caller-made primitives: spheres = n x (cx,cy,cz,radius,material), planes = n x
+ * (base xyz, u xyz, v xyz, material, type) — normal/D/w are computed like the reference's PlaneData
+ * constructor — and materials in the rt_material layout; the BVH is built by build_bvh(). */
+rtp_host_scene *rtp_host_scene_from_arrays(const float *spheres, int32_t num_spheres, const float *planes, int32_t num_planes,
+                                           const rt_material *materials, int32_t num_materials);
 void rtp_host_scene_free(rtp_host_scene *s);
 
 /* Arrays in the layouts rt_scene_create() takes; valid until the scene is freed. */

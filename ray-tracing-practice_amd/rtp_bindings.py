@@ -96,6 +96,8 @@ def host_lib():
         lib.rtp_host_scene_from_config.argtypes = [C.c_char_p, C.c_char_p]
         lib.rtp_host_scene_rtiow.restype = C.c_void_p
         lib.rtp_host_scene_rtiow.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32]
+        lib.rtp_host_scene_from_arrays.restype = C.c_void_p
+        lib.rtp_host_scene_from_arrays.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(Material), C.c_int32]
         lib.rtp_host_scene_free.argtypes = [C.c_void_p]
         lib.rtp_host_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         lib.rtp_host_scene_config.argtypes = [C.c_void_p, C.POINTER(ConfigInfo)]
@@ -171,6 +173,16 @@ class HostScene:
     @classmethod
     def rtiow(cls, seed=12345, half_extent=11, textured_quad=False, texture_size=1024):
         return cls(host_lib().rtp_host_scene_rtiow(seed, half_extent, int(textured_quad), texture_size))
+
+    @classmethod
+    def from_arrays(cls, spheres, planes, materials):
+        """spheres: [n,5] (cx,cy,cz,radius,material); planes: [n,11] (base,u,v,material,type);
+        materials: list of Material."""
+        sp = np.ascontiguousarray(np.asarray(spheres, dtype=np.float32).reshape(-1, 5))
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float32).reshape(-1, 11))
+        mats = (Material * max(len(materials), 1))(*materials)
+        return cls(host_lib().rtp_host_scene_from_arrays(sp.ctypes.data, sp.shape[0], pl.ctypes.data, pl.shape[0], mats,
+                                                         len(materials)))
 
     def frame_camera(self, frame=0):
         cam = CameraData()

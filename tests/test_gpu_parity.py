@@ -353,3 +353,51 @@ def test_stress_scene_at_4k_rows():
     assert t.scene_in_lds == 0
     for row in (5, 1080, 2100):
         assert_same_frame(fb[row:row + 1], ob.render(host, cam, row0=row, row1=row + 1, threads=8), f"4K row {row}")
+
+
+def _random_scene(rng, n_spheres, n_planes, axis_aligned=False):
+    mats = []
+    for _ in range(6):
+        t = int(rng.integers(0, 4))
+        mats.append(_material(t, albedo=rng.uniform(0.1, 1.0, 3), fuzz=float(rng.uniform(0, 0.7)), ir=float(rng.uniform(1.1, 2.0)),
+                              absorption=rng.uniform(0, 0.6, 3) if rng.random() < 0.5 else (0, 0, 0),
+                              emit=rng.uniform(0.5, 3.0, 3) if t == 3 else (0, 0, 0)))
+    spheres = np.zeros((n_spheres, 5), dtype=np.float32)
+    spheres[:, :3] = rng.uniform(-6, 6, (n_spheres, 3))
+    spheres[:, 3] = rng.uniform(0.05, 1.5, n_spheres)
+    spheres[:, 4] = rng.integers(0, len(mats), n_spheres)
+    planes = np.zeros((n_planes, 11), dtype=np.float32)
+    planes[:, :3] = rng.uniform(-6, 6, (n_planes, 3))
+    if axis_aligned:     # boxes thin in one axis, normals along axes: exercises the 1e-4 padding and 1/0 slabs
+        for k in range(n_planes):
+            a = int(rng.integers(0, 3))
+            u = np.zeros(3); v = np.zeros(3)
+            u[(a + 1) % 3] = rng.uniform(1, 4); v[(a + 2) % 3] = rng.uniform(1, 4)
+            planes[k, 3:6] = u; planes[k, 6:9] = v
+    else:
+        planes[:, 3:6] = rng.uniform(-3, 3, (n_planes, 3))
+        planes[:, 6:9] = rng.uniform(-3, 3, (n_planes, 3))
+    planes[:, 9] = rng.integers(0, len(mats), n_planes)
+    planes[:, 10] = rng.integers(0, 3, n_planes)
+    return rb.HostScene.from_arrays(spheres, planes, mats)
+
+
+def test_random_scenes_bit_identical():
+    """Randomised scenes (all materials, all plane types, absorbing glass, lights, random and
+    axis-aligned geometry, cameras inside the scene, rays with zero direction components):
+    per-pixel sums bit-identical to the oracle."""
+    rng = np.random.default_rng(2024)
+    for trial in range(10):
+        host = _random_scene(rng, int(rng.integers(1, 60)), int(rng.integers(0, 25)), axis_aligned=trial % 3 == 0)
+        dev = rb.DeviceScene(host, device=0)
+        eye = rng.uniform(-9, 9, 3)
+        if trial % 4 == 1:
+            eye = np.array([0.0, 8.0, 0.5])       # looks along -y: pixel columns with d.x == 0 exactly
+            target = np.array([0.0, 0.0, 0.5])
+        else:
+            target = rng.uniform(-2, 2, 3)
+        cam = rb.make_camera(int(rng.integers(33, 160)), int(rng.integers(17, 90)), float(rng.uniform(20, 100)), eye, target,
+                             rng.uniform(0, 1, 3), int(rng.integers(1, 7)), int(rng.integers(1, 30)))
+        fb, _ = dev.render_to_host(cam)
+        want = ob.render(host, cam, threads=8)
+        assert_same_frame(fb, want, f"random scene {trial}")
