@@ -257,11 +257,16 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     const uint64_t node_f4 = threaded ? ((uint64_t)P.num_tnodes + 1) * 2 : (uint64_t)P.num_internal * 4;
     const uint64_t scene_bytes = (node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
                                   ((uint64_t)P.num_spheres + 3) / 4) * 16;
-    // two workgroups per CU when both fit in LDS, else one, else tables stay in global memory
-    int wgs_per_cu = env_int("RTP_WGS_PER_CU", 0);
-    if (wgs_per_cu <= 0) wgs_per_cu = (2 * (scene_bytes + stack_bytes) <= kLdsLimit && 2 * rtk::kBlock <= 2048) ? RTP_MIN_WAVES * 256 / rtk::kBlock : 1;
-    if (wgs_per_cu < 1) wgs_per_cu = 1;
     const bool in_lds = !env_int("RTP_NO_LDS_SCENE", 0) && scene_bytes + stack_bytes <= kLdsLimit;
+    // workgroups per CU: what the register budget admits (RTP_MIN_WAVES waves per SIMD), unless two
+    // LDS-resident scene copies do not fit next to each other
+    int wgs_per_cu = env_int("RTP_WGS_PER_CU", 0);
+    if (wgs_per_cu <= 0) {
+        wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
+        const uint64_t per_wg = in_lds ? scene_bytes + stack_bytes : stack_bytes;
+        while (wgs_per_cu > 1 && (uint64_t)wgs_per_cu * per_wg > kLdsLimit) --wgs_per_cu;
+    }
+    if (wgs_per_cu < 1) wgs_per_cu = 1;
     const uint32_t lds_bytes = (uint32_t)(in_lds ? scene_bytes + stack_bytes : stack_bytes);
     if (lds_bytes > kLdsLimit) return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
     int wgs = sc->num_cus * wgs_per_cu;
