@@ -192,6 +192,56 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
             o[6] = bits_as_float(count | blocked);
             o[7] = bits_as_float(0);
         }
+
+        // ---- the same walk with EXPLICIT links, for scenes too big for LDS: the records of the top
+        // levels (breadth-first from the root) come first so the kernel can keep that "treelet" in
+        // LDS and read only deeper nodes through L1/L2; deeper records stay in depth-first order.
+        //   inner record: z = miss link, w = hit link (>= 0)
+        //   leaf record : z = next link (hit or miss), w = sign | (2*index+type+1)   (sign alone: a leaf
+        //                 with nothing to test — untyped, or an inner node hit_bvh prunes)
+        //   links are record indices; the end of the walk is the sentinel record at index count,
+        //   whose box is never hit and whose miss link is negative.
+        {
+            const int32_t want_top = 2048;                     // records kept in LDS at most (64 KB)
+            std::vector<int32_t> new_of(static_cast<size_t>(count), -1);       // DFS position → record index
+            std::vector<int32_t> bfs;
+            bfs.reserve(static_cast<size_t>(want_top));
+            if (count > 0) bfs.push_back(0);
+            for (size_t head = 0; head < bfs.size() && static_cast<int32_t>(bfs.size()) < want_top; ++head) {
+                const int32_t p = bfs[head];
+                const rt_bvh_node &n = d.nodes[order[static_cast<size_t>(p)]];
+                const bool expanded = n.left >= 0 && visit_sp[static_cast<size_t>(p)] + 2 <= 32;
+                if (!expanded) continue;
+                bfs.push_back(pos_of[static_cast<size_t>(n.left)]);
+                if (static_cast<int32_t>(bfs.size()) < want_top) bfs.push_back(pos_of[static_cast<size_t>(n.right)]);
+            }
+            int32_t next_index = 0;
+            for (int32_t p : bfs) new_of[static_cast<size_t>(p)] = next_index++;
+            out.num_top = next_index;
+            for (int32_t p = 0; p < count; ++p)
+                if (new_of[static_cast<size_t>(p)] < 0) new_of[static_cast<size_t>(p)] = next_index++;
+            auto link = [&](int32_t dfs_pos) { return dfs_pos == count ? count : new_of[static_cast<size_t>(dfs_pos)]; };
+            out.xnodes.resize(static_cast<size_t>(count + 1) * 8);
+            for (int32_t p = 0; p < count; ++p) {
+                const rt_bvh_node &n = d.nodes[order[static_cast<size_t>(p)]];
+                float *o = &out.xnodes[static_cast<size_t>(new_of[static_cast<size_t>(p)]) * 8];
+                for (int k = 0; k < 6; ++k) o[k] = n.box[k];
+                const bool expanded = n.left >= 0 && visit_sp[static_cast<size_t>(p)] + 2 <= 32;
+                o[6] = bits_as_float(link(skip[static_cast<size_t>(p)]));
+                if (expanded) {
+                    o[7] = bits_as_float(link(p + 1));
+                } else {
+                    int32_t leaf = blocked;
+                    if (n.left < 0 && (n.type == 0 || n.type == 1)) leaf |= 2 * n.right + n.type + 1;
+                    o[7] = bits_as_float(leaf);
+                }
+            }
+            float *o = &out.xnodes[static_cast<size_t>(count) * 8];
+            o[0] = 1e30f; o[1] = -1e30f; o[2] = 1e30f; o[3] = -1e30f; o[4] = 1e30f; o[5] = -1e30f;
+            o[6] = bits_as_float(count | blocked);
+            o[7] = bits_as_float(0);
+            out.xroot = count > 0 ? new_of[0] : count;
+        }
     }
 
     // ---- traversal tree

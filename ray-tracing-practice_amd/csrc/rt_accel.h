@@ -39,6 +39,10 @@ struct Packed {
     // index num_tnodes is an end sentinel whose box is never hit.
     std::vector<float> tnodes;
     int32_t num_tnodes = 0;
+    // The same walk with explicit hit/miss links and the top levels first (see rt_accel.cpp): used
+    // when the tables do not fit in LDS — records [0, num_top) are the LDS "treelet".
+    std::vector<float> xnodes;
+    int32_t num_top = 0, xroot = 0;
     int32_t root = kTraversalDone; // node code of the root (leaf code when the scene has one primitive)
     int32_t num_internal = 0;
     int32_t max_depth = 0;         // longest root→leaf path in internal nodes = traversal stack bound

@@ -53,8 +53,8 @@ bool threaded_mode() {
 
 struct rt_scene {
     int device = 0;
-    float4 *tnodes = nullptr;
-    int32_t num_tnodes = 0;
+    float4 *tnodes = nullptr, *xnodes = nullptr;
+    int32_t num_tnodes = 0, num_top = 0;
     float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
@@ -128,6 +128,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.local_rows = rt_shard_rows(cam->image_height, shard);
     P.nodes = sc->nodes; P.num_internal = sc->num_internal; P.root = sc->root;
     P.tnodes = sc->tnodes; P.num_tnodes = sc->num_tnodes;
+    P.xnodes = sc->xnodes; P.num_top = sc->num_top;
     P.spheres = sc->spheres; P.num_spheres = sc->num_spheres;
     P.planes = sc->planes; P.num_planes = sc->num_planes;
     P.materials = sc->materials; P.num_materials = sc->num_materials;
@@ -188,6 +189,8 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
     if ((st = upload(pk.tnodes, (void **)&sc->tnodes)) != RT_OK) return bail(st);
     sc->num_tnodes = pk.num_tnodes;
+    if ((st = upload(pk.xnodes, (void **)&sc->xnodes)) != RT_OK) return bail(st);
+    sc->num_top = pk.num_top;
     if ((st = upload(pk.spheres, (void **)&sc->spheres)) != RT_OK) return bail(st);
     if ((st = upload(pk.planes, (void **)&sc->planes)) != RT_OK) return bail(st);
     if ((st = upload(pk.materials, (void **)&sc->materials)) != RT_OK) return bail(st);
@@ -210,6 +213,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
 rt_status rt_scene_destroy(rt_scene *sc) {
     if (!sc) return RT_OK;
     (void)hipFree(sc->tnodes);
+    (void)hipFree(sc->xnodes);
     (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
@@ -258,16 +262,19 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     const uint64_t scene_bytes = (node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
                                   ((uint64_t)P.num_spheres + 3) / 4) * 16;
     const bool in_lds = !env_int("RTP_NO_LDS_SCENE", 0) && scene_bytes + stack_bytes <= kLdsLimit;
+    // big scene, reference-order walk: the top of the tree (explicit-link records [0, num_top)) is staged in LDS
+    if (in_lds || !threaded || env_int("RTP_NO_TREELET", 0)) P.num_top = 0;
+    const uint32_t treelet_bytes = (uint32_t)P.num_top * 32u;
     // workgroups per CU: what the register budget admits (RTP_MIN_WAVES waves per SIMD), unless two
     // LDS-resident scene copies do not fit next to each other
     int wgs_per_cu = env_int("RTP_WGS_PER_CU", 0);
     if (wgs_per_cu <= 0) {
         wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
-        const uint64_t per_wg = in_lds ? scene_bytes + stack_bytes : stack_bytes;
+        const uint64_t per_wg = in_lds ? scene_bytes + stack_bytes : stack_bytes + treelet_bytes;
         while (wgs_per_cu > 1 && (uint64_t)wgs_per_cu * per_wg > kLdsLimit) --wgs_per_cu;
     }
     if (wgs_per_cu < 1) wgs_per_cu = 1;
-    const uint32_t lds_bytes = (uint32_t)(in_lds ? scene_bytes + stack_bytes : stack_bytes);
+    const uint32_t lds_bytes = (uint32_t)(in_lds ? scene_bytes + stack_bytes : stack_bytes + treelet_bytes);
     if (lds_bytes > kLdsLimit) return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
     int wgs = sc->num_cus * wgs_per_cu;
     const uint32_t max_wgs = (uint32_t)(((uint64_t)P.local_rows * P.width * (P.spp < 64 ? P.spp : 64) + rtk::kBlock - 1) / rtk::kBlock);
