@@ -97,7 +97,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    backend = os.environ.get("RTP_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 flow on one GPU
+    if world > 1 and backend != "nccl":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -106,6 +110,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()          # (rehearsals may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     rb._check(rb.amd_lib().rt_set_device(local_rank), "rt_set_device")
 
@@ -122,7 +127,11 @@ def main():
 
     def step(record):
         dev.render(cam, fb.data_ptr(), shard=shard, stream=stream, sync=False)
-        frame = fp.gather_frame(fb, HEIGHT, band) if world > 1 else fb
+        if world > 1 and backend != "nccl":
+            torch.cuda.synchronize()
+            frame = fp.gather_frame(fb.cpu(), HEIGHT, band)          # gloo rehearsal: staged through the host
+        else:
+            frame = fp.gather_frame(fb, HEIGHT, band) if world > 1 else fb
         if record:
             t = dev.last_timing()     # hipEvent pairs recorded on `stream`: whole call, and around each trace launch
             kernel_ms.append(t.kernel_ms)
@@ -146,7 +155,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,6 +174,13 @@ def main():
                        "traversal": os.environ.get("RTP_TRAVERSAL", "threaded")},
         }
         base, st = (None, None)
+        if world > 1 and os.environ.get("RTP_BENCH_CHECK"):
+            import oracle_bindings as ob       # rehearsal only: the assembled frame against the checker
+            got = frame.detach().cpu().numpy()
+            rows = [HEIGHT // 3, HEIGHT - 7]
+            out["checked_rows"] = {"rows": rows, "assembled_frame_bit_identical": bool(all(
+                np.array_equal(ob.render(host, cam, row0=r, row1=r + 1, threads=host_threads()).view(np.uint32),
+                               got[r:r + 1].view(np.uint32)) for r in rows))}
         if world == 1 and not args.no_cpu_baseline:
             base, st = cpu_baseline(host, host_threads(), frame=frame.detach().cpu().numpy(), gpu_cam=cam)
             out["cpu_baseline"] = base
@@ -180,7 +196,7 @@ def main():
         achieved = bytes_per_sample * (local_samples / max(n_launch, 1)) / (launch_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1 and args.spp == SPP:
             try:
                 traffic = json.load(open(tpath)).get("bytes_per_trace_launch_1920x1080x64")
             except Exception:
