@@ -187,6 +187,13 @@ rt_status rt_render_to_host(rt_scene *scene, const rt_camera_data *cam, const rt
 rt_status rt_trace_samples(rt_scene *scene, const rt_camera_data *cam, int32_t n, const int32_t *ijs,
                            float *radiance, int32_t *rays, uint32_t *final_seed);
 
+/* Ray-level probe used by the parity tests: hit_scene (include/scene.h:23-35) for n arbitrary rays
+ * (origins/directions = 3*n floats each, HOST memory) with the interval (0.001, 1e30) ray_color
+ * uses.  hit[k] = 1/0; t[k] and prim[k] (2*index + type, type 0 sphere / 1 plane) are written for
+ * hits only. */
+rt_status rt_closest_hits(rt_scene *scene, int32_t n, const float *origins, const float *directions,
+                          int32_t *hit, float *t, int32_t *prim);
+
 /* Device buffer management for hosts that do not link the HIP runtime themselves: replace
  * gpu_render's cudaMalloc / cudaFree of the framebuffer (src/camera.cu:295,348) and
  * Camera::render's cudaMemcpy device→host (src/camera.cu:209). */

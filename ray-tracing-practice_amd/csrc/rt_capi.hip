@@ -472,6 +472,48 @@ rt_status rt_trace_samples(rt_scene *sc, const rt_camera_data *cam, int32_t n, c
     return RT_OK;
 }
 
+rt_status rt_closest_hits(rt_scene *sc, int32_t n, const float *origins, const float *directions, int32_t *hit, float *t, int32_t *prim) {
+    if (!sc || n < 0 || (n > 0 && (!origins || !directions || !hit || !t || !prim))) return fail(RT_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return RT_OK;
+    rt_camera_data cam{};
+    cam.image_width = cam.image_height = 1;
+    cam.samples_per_pixel = cam.max_depth = 1;
+    rtk::KParams P;
+    rt_status st = fill_params(sc, &cam, nullptr, P);
+    if (st != RT_OK) return st;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    int32_t *d_hit = nullptr, *d_prim = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_hit); (void)hipFree(d_prim); };
+    const size_t n3 = (size_t)n * 12, n1 = (size_t)n * 4;
+    if (hipMalloc((void **)&d_o, n3) != hipSuccess || hipMalloc((void **)&d_d, n3) != hipSuccess || hipMalloc((void **)&d_t, n1) != hipSuccess ||
+        hipMalloc((void **)&d_hit, n1) != hipSuccess || hipMalloc((void **)&d_prim, n1) != hipSuccess) {
+        cleanup();
+        return fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    }
+    hipError_t e = hipMemcpy(d_o, origins, n3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, directions, n3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_t, 0, n1);
+    if (e == hipSuccess) e = hipMemset(d_prim, 0xff, n1);
+    const uint32_t lds = 4u * (uint32_t)P.stack_levels * rtk::kWave * 4u;
+    if (e == hipSuccess && lds > kLdsLimit) { cleanup(); return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack"); }
+    if (e == hipSuccess) {
+        if (threaded_mode()) {
+            hipLaunchKernelGGL(rtk::closest_hit_kernel<true>, dim3((n + 255) / 256), dim3(256), lds, 0, P, d_o, d_d, n, d_hit, d_t, d_prim);
+        } else {
+            (void)hipFuncSetAttribute((const void *)rtk::closest_hit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(rtk::closest_hit_kernel<false>, dim3((n + 255) / 256), dim3(256), lds, 0, P, d_o, d_d, n, d_hit, d_t, d_prim);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(hit, d_hit, n1, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(t, d_t, n1, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(prim, d_prim, n1, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(RT_ERR_HIP, std::string("closest-hit probe: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
 rt_status rt_device_alloc(uint64_t bytes, void **out) {
     if (!out) return fail(RT_ERR_INVALID_ARG, "null argument");
     *out = nullptr;

@@ -76,7 +76,7 @@ assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
 RTP_AMD_SYMBOLS = [
     "rt_set_device", "rt_scene_create", "rt_scene_destroy", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
     "rt_last_timing",
-    "rt_render_to_host", "rt_trace_samples", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
+    "rt_render_to_host", "rt_trace_samples", "rt_closest_hits", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
     "rt_get_last_error_string", "rt_version_string",
 ]
 
@@ -134,6 +134,7 @@ def amd_lib():
                                           C.POINTER(Timing)]
         lib.rt_trace_samples.argtypes = [C.c_void_p, C.POINTER(CameraData), C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
+        lib.rt_closest_hits.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_device_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
         lib.rt_device_free.argtypes = [C.c_void_p]
         lib.rt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -277,6 +278,17 @@ class DeviceScene:
         _check(amd_lib().rt_trace_samples(self._h, C.byref(cam), n, ijs.ctypes.data, rad.ctypes.data, rays.ctypes.data,
                                           seeds.ctypes.data), "rt_trace_samples")
         return rad, rays, seeds
+
+    def closest_hits(self, origins, directions):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        hit = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float32)
+        prim = np.zeros(n, dtype=np.int32)
+        _check(amd_lib().rt_closest_hits(self._h, n, o.ctypes.data, d.ctypes.data, hit.ctypes.data, t.ctypes.data,
+                                         prim.ctypes.data), "rt_closest_hits")
+        return hit, t, prim
 
     def close(self):
         if self._h:

@@ -401,3 +401,90 @@ def test_random_scenes_bit_identical():
         fb, _ = dev.render_to_host(cam)
         want = ob.render(host, cam, threads=8)
         assert_same_frame(fb, want, f"random scene {trial}")
+
+
+def _oracle_hits(host, origins, directions):
+    lib = ob.lib()
+    n = origins.shape[0]
+    hit = np.zeros(n, dtype=np.int32)
+    t = np.zeros(n, dtype=np.float32)
+    prim = np.zeros(n, dtype=np.int32)
+    tt, ty, ix = C.c_float(), C.c_int(), C.c_int()
+    for k in range(n):
+        o = np.ascontiguousarray(origins[k], dtype=np.float32)
+        d = np.ascontiguousarray(directions[k], dtype=np.float32)
+        if lib.orc_closest_hit(C.byref(host.desc), o.ctypes.data, d.ctypes.data, C.byref(tt), C.byref(ty), C.byref(ix)):
+            hit[k], t[k], prim[k] = 1, tt.value, 2 * ix.value + ty.value
+    return hit, t, prim
+
+
+def test_hit_scene_on_crafted_rays():
+    """hit_bvh / AABB::hit / hit_sphere / hit_plane at the ray level (rt_closest_hits against the
+    oracle's hit_scene), on the inputs where float semantics bite: direction components that are
+    exactly zero (1/0 = inf slabs), origins exactly on box planes (0 * inf = NaN), origins inside
+    and on spheres, tangent rays, rays along plane surfaces, huge and tiny directions, rays that
+    start behind everything."""
+    rng = np.random.default_rng(99)
+    mats = [_material(0, albedo=(0.5, 0.5, 0.5))]
+    spheres = np.array([[0, 0, 0, 1, 0], [3, 0, 0, 0.5, 0], [0, 4, 0, 2, 0], [0, 0, -1000, 999, 0], [2, 2, 2, 0.05, 0],
+                        [-3, -3, 0.5, 0.5, 0], [5, 5, 5, 1e-3, 0]], dtype=np.float32)
+    planes = np.array([[-2, -2, 3, 4, 0, 0, 0, 4, 0, 0, 0],          # axis-aligned quad z = 3
+                       [-2, -2, -3, 4, 0, 0, 0, 4, 0, 0, 2],         # triangle z = -3
+                       [4, -1, -1, 0, 2, 0, 0, 0, 2, 0, 1],          # ellipse x = 4
+                       [-6, 0, 0, 1, 1, 0, 0, 1, 1, 0, 0]], dtype=np.float32)     # tilted quad
+    host = rb.HostScene.from_arrays(spheres, planes, mats)
+    dev = rb.DeviceScene(host, device=0)
+    O, D = [], []
+    axes = np.eye(3, dtype=np.float32)
+    for c in spheres[:, :3]:
+        for a in axes:
+            for sgn in (1.0, -1.0):
+                O.append(c + sgn * 7 * a); D.append(-sgn * a)                      # through the centre along an axis: two zero components
+                O.append(c + sgn * 7 * a + np.roll(a, 1)); D.append(-sgn * a)      # offset by exactly the unit sphere's radius: tangent
+        O.append(c.copy()); D.append(np.array([1, 0, 0], np.float32))              # origin at the centre
+        O.append(c + np.array([0.25, 0, 0], np.float32)); D.append(np.array([0, 1, 1], np.float32))   # inside
+    for s in spheres:                                                               # origins exactly on the leaf box faces
+        lo, hi = s[:3] - s[3], s[:3] + s[3]
+        for a in range(3):
+            p = s[:3].copy(); p[a] = lo[a]
+            d = np.ones(3, np.float32); d[a] = 0.0
+            O.append(p.copy()); D.append(d.copy())                                  # on the face, moving inside the face plane
+            p[a] = hi[a]; O.append(p.copy()); D.append(-d)
+    for z in (3.0, -3.0):                                                           # along and across the flat quads' padded boxes
+        O.append(np.array([-5, 0, z], np.float32)); D.append(np.array([1, 0, 0], np.float32))
+        O.append(np.array([0, 0, z + 5], np.float32)); D.append(np.array([0, 0, -1], np.float32))
+        O.append(np.array([0, 0, z], np.float32)); D.append(np.array([0.3, 0.1, 0], np.float32))
+        O.append(np.array([-2, -2, z + 1], np.float32)); D.append(np.array([0, 0, -1], np.float32))     # exactly through a corner
+        O.append(np.array([2, -2, z + 1], np.float32)); D.append(np.array([0, 0, -2.5], np.float32))     # exactly through an edge end
+    for scale in (1e-20, 1e-6, 1e6, 1e18):                                          # tiny / huge direction lengths
+        O.append(np.array([-9, 0.1, 0.2], np.float32)); D.append(np.array([scale, 0, 0], np.float32))
+        O.append(np.array([0.3, 0.2, 40], np.float32)); D.append(np.array([0, scale * 0.01, -scale], np.float32))
+    O.append(np.array([0, 0, 0], np.float32)); D.append(np.array([0, 0, 0], np.float32))       # null direction
+    O.append(np.array([50, 50, 50], np.float32)); D.append(np.array([1, 1, 1], np.float32))    # everything behind
+    for _ in range(3000):                                                           # plus random rays, some axis-parallel
+        o = rng.uniform(-8, 8, 3).astype(np.float32)
+        d = rng.normal(size=3).astype(np.float32)
+        if rng.random() < 0.3:
+            d[int(rng.integers(0, 3))] = 0.0
+        if rng.random() < 0.1:
+            d[int(rng.integers(0, 3))] = -0.0
+        O.append(o); D.append(d)
+    O = np.array(O, dtype=np.float32); D = np.array(D, dtype=np.float32)
+    hit, t, prim = dev.closest_hits(O, D)
+    ohit, ot, oprim = _oracle_hits(host, O, D)
+    assert np.array_equal(hit, ohit), np.where(hit != ohit)[0][:10]
+    h = hit == 1
+    assert np.array_equal(t[h].view(np.uint32), ot[h].view(np.uint32)), np.where(t[h] != ot[h])[0][:10]
+    assert np.array_equal(prim[h], oprim[h])
+    assert h.sum() > 1000 and (~h).sum() > 500
+    # the same on the benchmark scene (ground sphere of radius 1000 under tangent small spheres)
+    host2 = rb.HostScene.rtiow()
+    dev2 = rb.DeviceScene(host2, device=0)
+    O2 = rng.uniform(-12, 12, (6000, 3)).astype(np.float32); O2[:, 2] = np.abs(O2[:, 2]) * 0.2 + 1e-3
+    D2 = rng.normal(size=(6000, 3)).astype(np.float32)
+    D2[::5, 2] = -np.abs(D2[::5, 2])
+    hit, t, prim = dev2.closest_hits(O2, D2)
+    ohit, ot, oprim = _oracle_hits(host2, O2, D2)
+    assert np.array_equal(hit, ohit)
+    h = hit == 1
+    assert np.array_equal(t[h].view(np.uint32), ot[h].view(np.uint32)) and np.array_equal(prim[h], oprim[h])
