@@ -201,12 +201,21 @@ def main():
                 traffic = json.load(open(tpath)).get("bytes_per_trace_launch_1920x1080x64")
             except Exception:
                 traffic = None
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu_util.json")
+        if os.path.exists(vpath) and world == 1 and args.spp == SPP:
+            try:
+                v = json.load(open(vpath))
+                valu = {k: v[k] for k in ("valu_issue_utilisation", "valu_lane_utilisation", "valu_roofline_frac")}
+            except Exception:
+                valu = None
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "rtk::render_kernel<true,true>", "launches_per_step": n_launch, "launch_ms": round(launch_ms, 3),
             "step_kernels_ms": round(k_ms, 3),
             "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
+            "valu_side_from_committed_pmc": valu,
             "note": "algorithmic bytes (node/sphere/material records the reference's traversal touches) are served "
                     "from LDS, not HBM; see DESIGN.md 'Roofline' for the VALU-side reading",
         }
