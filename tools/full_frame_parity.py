@@ -3,9 +3,17 @@ the CPU oracle, every pixel, bit for bit.  ~90 s of 16 host threads."""
 import json, os, sys, time, hashlib
 sys.path.insert(0,'tests'); sys.path.insert(0,'ray-tracing-practice_amd')
 import oracle_bindings as ob, rtp_bindings as rb, numpy as np
-W,H,SPP=1920,1080,int(os.environ.get('SPP',500))
-host=rb.HostScene.rtiow(); dev=rb.DeviceScene(host,device=0)
-cam=rb.rtiow_camera(W,H,SPP,50)
+if os.environ.get('SCENE')=='default':      # the reference's `main --default` animation, frame FRAME
+    host=rb.HostScene.from_config(rb.host_lib().rtp_host_default_config().decode())
+    cam=host.frame_camera(int(os.environ.get('FRAME',0)))
+    W,H,SPP=cam.image_width,cam.image_height,cam.samples_per_pixel
+    label=f'reference default config frame {os.environ.get("FRAME",0)}: polyhedra scene {W}x{H} {SPP} spp depth {cam.max_depth}'
+else:
+    W,H,SPP=1920,1080,int(os.environ.get('SPP',500))
+    host=rb.HostScene.rtiow()
+    cam=rb.rtiow_camera(W,H,SPP,50)
+    label=f'S-rtiow {W}x{H} {SPP} spp 50 bounces'
+dev=rb.DeviceScene(host,device=0)
 got,tm=dev.render_to_host(cam)
 print('gpu frame', tm.kernel_ms,'ms', flush=True)
 t=time.time()
@@ -16,7 +24,7 @@ for r0 in range(0,H,60):
     eq=(want.view(np.uint32)==g.view(np.uint32)).all(-1)
     bad+=int((~eq).sum()); maxabs=max(maxabs,float(np.abs(want-g).max()))
     print('rows',r0,'bad so far',bad,'elapsed %.0fs'%(time.time()-t), flush=True)
-res={'config':f'S-rtiow {W}x{H} {SPP} spp 50 bounces','pixels':W*H,'samples':W*H*SPP,'pixels_differing':bad,'max_abs_diff':maxabs,
+res={'config':label,'pixels':W*H,'samples':W*H*SPP,'pixels_differing':bad,'max_abs_diff':maxabs,
      'gpu_kernel_ms':tm.kernel_ms,'oracle_seconds':time.time()-t,'frame_sha256':hashlib.sha256(got.tobytes()).hexdigest()}
 print(json.dumps(res))
-json.dump(res,open('gpurun_out/full_frame_parity.json','w'),indent=1)
+json.dump(res,open('gpurun_out/full_frame_parity_%s.json'%os.environ.get('SCENE','rtiow'),'w'),indent=1)
