@@ -190,7 +190,7 @@ def main():
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         tr_ms = float(np.mean(trace_ms)) if trace_ms else float("nan")
         n_launch = int(launches[0]) if launches else 0
-        # one frame = n_launch launches of the trace kernel (64 samples per pixel each);
+        # one frame = n_launch launches of the trace kernel (a pass of samples per pixel each);
         # achieved = algorithmic bytes of one launch / its mean duration
         launch_ms = tr_ms / max(n_launch, 1)
         achieved = bytes_per_sample * (local_samples / max(n_launch, 1)) / (launch_ms * 1e-3) / 1e9
@@ -198,7 +198,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.spp == SPP:
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_trace_launch_1920x1080x64")
+                tj = json.load(open(tpath))       # measured for one launch shape: only quoted when this run has it
+                traffic = tj.get("bytes_per_trace_launch") if tj.get("trace_launches_per_frame") == n_launch else None
             except Exception:
                 traffic = None
         valu = None

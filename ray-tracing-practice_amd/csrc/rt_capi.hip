@@ -37,7 +37,7 @@ int env_int(const char *name, int fallback) {
 }
 
 constexpr uint32_t kLdsLimit = 160 * 1024;
-constexpr int kMaxPasses = 1024;        // 64 samples per pass
+constexpr int kMaxPasses = 1024;        // >= 64 samples per pass
 constexpr int kTimedPasses = 64;        // trace launches individually timed per call
 
 // Traversal mode.  "threaded" (default): the caller's tree in the reference's own visit order —
@@ -281,21 +281,44 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
     if (wgs < 1) wgs = 1;
 
+    // Samples per pass: as many as the slab budget admits (default 20 GiB of the 288 GB, RTP_SLAB_GIB),
+    // at least 64, and few enough for the 32-bit work index and its reciprocal-multiply division.
+    // Fewer, larger launches amortise the end-of-launch tail — on a row shard of an N-GPU frame
+    // the pass grows N-fold, so a launch keeps the size it has on one GPU.
+    const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
+    int pass_size = P.spp;
+    {
+        const uint64_t budget = (uint64_t)(env_int("RTP_SLAB_GIB", 20) > 0 ? env_int("RTP_SLAB_GIB", 20) : 1) << 30;
+        uint64_t fit = budget / ((uint64_t)num_pixels * sizeof(float4));
+        const uint64_t index_fit = (((uint64_t)1 << 30) - 64) / num_pixels;     // total_work + 64 <= 2^30
+        if (fit > index_fit) fit = index_fit;
+        if (fit < 64) fit = 64;
+        if ((uint64_t)pass_size > fit) pass_size = (int)fit;
+        if (const int forced = env_int("RTP_PASS_SPP", 0)) pass_size = forced < P.spp ? forced : P.spp;
+        rtk::Magic probe;
+        while (pass_size > 64 && !make_magic((uint32_t)pass_size, (uint64_t)num_pixels * pass_size + 64, probe)) --pass_size;
+    }
     // workspace: one float4 per (local pixel, slot)
-    const size_t need = (size_t)P.local_rows * (size_t)P.width * (size_t)(P.spp < 64 ? P.spp : 64);
+    size_t need = (size_t)num_pixels * (size_t)pass_size;
     if (sc->slab_float4s < need) {
         HIP_TRY(hipStreamSynchronize(stream));
         (void)hipFree(sc->slab);
         sc->slab = nullptr;
         sc->slab_float4s = 0;
-        HIP_TRY(hipMalloc((void **)&sc->slab, need * sizeof(float4)));
+        for (;;) {      // a device short of memory gets shorter passes, not an error
+            const hipError_t e = hipMalloc((void **)&sc->slab, need * sizeof(float4));
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+            if (e != hipErrorOutOfMemory || pass_size <= 64) HIP_TRY(e);
+            pass_size = pass_size / 2 < 64 ? 64 : pass_size / 2;
+            need = (size_t)num_pixels * (size_t)pass_size;
+        }
         sc->slab_float4s = need;
     }
     P.slab = sc->slab;
-    P.num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
-    const int passes = (P.spp + 63) / 64;
+    P.num_pixels = num_pixels;
+    const int passes = (P.spp + pass_size - 1) / pass_size;
     if (passes > kMaxPasses) return fail(RT_ERR_UNSUPPORTED, "samples_per_pixel above 65536");
-    const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
 
     HIP_TRY(hipMemsetAsync(sc->queue, 0, (kMaxPasses + 16) * 4, stream));
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
@@ -348,8 +371,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         // samples [pass_first, pass_first + pass_count) of every pixel, traced in any order into the slab …
         const bool timed_pass = pass < kTimedPasses;
         if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[2 * pass], stream));
-        P.pass_first = pass * 64;
-        P.pass_count = P.spp - P.pass_first < 64 ? P.spp - P.pass_first : 64;
+        P.pass_first = pass * pass_size;
+        P.pass_count = P.spp - P.pass_first < pass_size ? P.spp - P.pass_first : pass_size;
         P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
         if (!make_magic((uint32_t)P.pass_count, (uint64_t)P.total_work + 64, P.magic_count))
             return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");

@@ -124,6 +124,25 @@ def test_samples_accumulate_in_order(rtiow):
         assert np.array_equal(bits(acc), bits(fb[j, i]))
 
 
+def test_pass_size_does_not_change_the_frame(rtiow):
+    """rt_render cuts the samples of a pixel into passes sized by the slab budget; whatever the
+    cut (one pass of 150, 64+64+22, 100+50, 7-sample passes), the in-order sum is the same bits,
+    and equals the oracle's on a row band."""
+    host, dev = rtiow
+    cam = rb.rtiow_camera(96, 50, 150, 50)
+    want, t = dev.render_to_host(cam)
+    assert t.trace_launches == 1
+    assert_same_frame(want[20:26], ob.render(host, cam, row0=20, row1=26, threads=8), "one pass of 150 spp")
+    try:
+        for forced, launches in ((64, 3), (100, 2), (7, 22)):
+            os.environ["RTP_PASS_SPP"] = str(forced)
+            got, t = dev.render_to_host(cam)
+            assert t.trace_launches == launches
+            assert_same_frame(got, want, f"passes of {forced} spp")
+    finally:
+        os.environ.pop("RTP_PASS_SPP", None)
+
+
 def test_sharded_render_equals_full_frame(rtiow):
     host, dev = rtiow
     cam = rb.rtiow_camera(200, 117, 3, 50)       # width and height not multiples of 8
