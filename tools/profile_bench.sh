@@ -11,11 +11,11 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 4 --warmup 0 --no-cpu-baseline"
 ONE="python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
 echo "trace done"
 pmc() {  # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" -d "$OUT/$name" -o pmc -- $ONE > "$OUT/$name.log" 2>&1
+    rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o pmc -- $ONE > "$OUT/$name.log" 2>&1
     echo "$name done"
 }
 pmc fetch FETCH_SIZE

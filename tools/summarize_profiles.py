@@ -78,7 +78,8 @@ util = {
     "valu_wave_instructions_per_launch": v[("trace", "SQ_INSTS_VALU")],
     "shader_cycles_per_launch": cycles,
     "clock_ghz": round(cycles / (launch_ms * 1e6), 3),
-    "wave_cycles_waiting_frac": round(q[("trace", "SQ_WAIT_INST_ANY")] / v[("trace", "SQ_WAVE_CYCLES")], 3),
+    "wave_cycles_in_waitcnt_frac": round(q[("trace", "SQ_WAIT_ANY")] / v[("trace", "SQ_WAVE_CYCLES")], 3),
+    "wave_cycles_issue_stalled_frac": round(q[("trace", "SQ_WAIT_INST_ANY")] / v[("trace", "SQ_WAVE_CYCLES")], 3),
     "wave_cycles_issuing_frac": round(q[("trace", "SQ_ACTIVE_INST_ANY")] / v[("trace", "SQ_WAVE_CYCLES")], 3),
     "lds_bank_conflict_cycles_per_lds_active": round(v[("trace", "SQ_LDS_BANK_CONFLICT")] / max(q[("trace", "SQ_LDS_IDX_ACTIVE")], 1.0), 3),
 }
