@@ -216,6 +216,9 @@ static int hit_plane(const ray *r, float tmin, float tmax, hitrec *rec, const rt
  * exact-t ties, so this restatement always visits the left child first. */
 static int hit_bvh(const rt_scene_desc *sc, const ray *r, float tmin, float tmax, hitrec *rec,
                    int *prim_type, int *prim_index, orc_stats *st) {
+#ifdef ORC_STUDY_HOOK      /* developer studies (tools/) see every ray the path loop casts */
+    ORC_STUDY_HOOK(sc, r);
+#endif
     int stack[32];
     int sp = 0;
     stack[sp++] = 0;

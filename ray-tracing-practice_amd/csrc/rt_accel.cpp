@@ -244,11 +244,129 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
         }
     }
 
+    // ---- guarded mode: eligibility, per-sphere inflation, exact leaf boxes for the final check
+    if (mode == TreeMode::Guarded) {
+        Packed::Guard &g = out.guard;
+        std::string why;
+        std::vector<int32_t> leaf_of(static_cast<size_t>(d.num_spheres), -1);
+        if (d.num_planes > 0) why = "scene has planes";
+        else if (leaves.empty()) why = "no primitives";
+        else if (d.num_spheres >= (1 << 24)) why = "too many spheres";
+        for (int k = 0; k < d.num_nodes && why.empty(); ++k) {
+            if (!reachable[static_cast<size_t>(k)]) continue;
+            const rt_bvh_node &n = d.nodes[k];
+            if (depth[static_cast<size_t>(k)] + 2 > 32) why = "tree deeper than hit_bvh's stack";       // the reference prunes silently there
+            for (int a = 0; a < 6 && why.empty(); ++a) if (!std::isfinite(n.box[a])) why = "non-finite box";
+            if (n.left < 0) {
+                if (n.type != 0) { why = "leaf that is not a sphere"; break; }
+                if (leaf_of[static_cast<size_t>(n.right)] >= 0) { why = "sphere referenced by two leaves"; break; }
+                leaf_of[static_cast<size_t>(n.right)] = k;
+                const rt_sphere &s = d.spheres[n.right];
+                if (!(s.radius > 0) || !std::isfinite(s.radius)) { why = "sphere radius not positive"; break; }
+                for (int a = 0; a < 3; ++a) {
+                    const float c = s.center.e[a];
+                    if (!std::isfinite(c)) { why = "non-finite sphere centre"; break; }
+                    // the leaf box must hold the sphere (up to the rounding of c -/+ r)
+                    const float tol = 4.0f * 5.9604645e-8f * (fabsf(c) + s.radius);
+                    if (n.box[2 * a] > c - s.radius + tol || n.box[2 * a + 1] < c + s.radius - tol) why = "leaf box does not contain its sphere";
+                }
+            } else {
+                for (int child : {n.left, n.right}) {
+                    const rt_bvh_node &c = d.nodes[child];
+                    for (int a = 0; a < 3; ++a)
+                        if (c.box[2 * a] < n.box[2 * a] || c.box[2 * a + 1] > n.box[2 * a + 1]) why = "child box not inside its parent's";
+                }
+            }
+        }
+        if (why.empty()) {
+            // bounding sphere of everything a path can start from (surfaces of all spheres)
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (const LeafRef &l : leaves)
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], l.box[2 * a]); hi[a] = fmaxf(hi[a], l.box[2 * a + 1]); }
+            const double C[3] = {0.5 * (double(lo[0]) + hi[0]), 0.5 * (double(lo[1]) + hi[1]), 0.5 * (double(lo[2]) + hi[2])};
+            auto dist = [](const double a[3], const float b[3]) {
+                return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+            };
+            double r_all = 0;
+            for (int i = 0; i < d.num_spheres; ++i)
+                if (leaf_of[static_cast<size_t>(i)] >= 0) r_all = std::max(r_all, dist(C, d.spheres[i].center.e) + d.spheres[i].radius);
+            // class L: the margin for ANY origin on a scene surface stays below 5 % of the radius
+            std::vector<char> large(static_cast<size_t>(d.num_spheres), 0);
+            std::vector<double> eps(static_cast<size_t>(d.num_spheres), 0.0);
+            float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            double r_min_small = INFINITY;
+            for (int i = 0; i < d.num_spheres; ++i) {
+                if (leaf_of[static_cast<size_t>(i)] < 0) continue;
+                const rt_sphere &s = d.spheres[i];
+                // any point of a scene surface is within r_all of C; 25 % on top for the camera (checked per render)
+                const double reach = 1.25 * (dist(C, s.center.e) + r_all);
+                const double e = double(kGuardGamma) * reach * reach / (2.0 * s.radius);
+                if (e <= 0.05 * s.radius) {
+                    large[static_cast<size_t>(i)] = 1;
+                    eps[static_cast<size_t>(i)] = e;
+                    g.large.insert(g.large.end(), {s.center.e[0], s.center.e[1], s.center.e[2], static_cast<float>(reach)});
+                } else {
+                    g.num_small++;
+                    r_min_small = std::min(r_min_small, double(s.radius));
+                    for (int a = 0; a < 3; ++a) { slo[a] = fminf(slo[a], s.center.e[a]); shi[a] = fmaxf(shi[a], s.center.e[a]); }
+                }
+            }
+            if (g.large.size() > 4 * 64) why = "too many large spheres for the per-render camera check";
+            if (why.empty() && g.num_small > 0) {
+                const double sc[3] = {0.5 * (double(slo[0]) + shi[0]), 0.5 * (double(slo[1]) + shi[1]), 0.5 * (double(slo[2]) + shi[2])};
+                double rs = 0;
+                for (int i = 0; i < d.num_spheres; ++i)
+                    if (leaf_of[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
+                        rs = std::max(rs, dist(sc, d.spheres[i].center.e) + d.spheres[i].radius);
+                // origins within d0 of the centre: margin 4 % of the smallest radius, but never less than the
+                // cluster itself (paths start on its surfaces)
+                double reach = std::sqrt(0.08 * r_min_small * r_min_small / double(kGuardGamma));
+                if (reach < 2.0 * rs) reach = 2.0 * rs;
+                const double d0 = reach - rs;
+                for (int i = 0; i < d.num_spheres; ++i)
+                    if (leaf_of[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
+                        eps[static_cast<size_t>(i)] = double(kGuardGamma) * reach * reach / (2.0 * d.spheres[i].radius);
+                for (int a = 0; a < 3; ++a) g.center[a] = static_cast<float>(sc[a]);
+                g.d0_sq = static_cast<float>(d0 * d0 * (1.0 - 1e-6));
+                g.cluster_radius = static_cast<float>(rs * (1.0 + 1e-6));
+                g.far_k = static_cast<float>(double(kGuardGamma) / (2.0 * r_min_small) * (1.0 + 1e-6));
+                for (int i = 0; i < d.num_spheres; ++i) {
+                    if (leaf_of[static_cast<size_t>(i)] < 0 || large[static_cast<size_t>(i)]) continue;
+                    const float *b = d.nodes[leaf_of[static_cast<size_t>(i)]].box;
+                    for (int a = 0; a < 3; ++a) { slo[a] = fminf(slo[a], b[2 * a]); shi[a] = fmaxf(shi[a], b[2 * a + 1]); }
+                }
+                for (int a = 0; a < 3; ++a) { g.box[2 * a] = slo[a]; g.box[2 * a + 1] = shi[a]; }
+            } else if (why.empty()) {
+                g.d0_sq = INFINITY;       // no small spheres: no far-origin test
+            }
+            if (why.empty()) {
+                // inflate the leaf boxes the traversal tree is built from; keep the exact ones for the final check
+                out.leaf_boxes.assign(static_cast<size_t>(d.num_spheres) * 8, 0.0f);
+                for (LeafRef &l : leaves) {
+                    const int32_t i = (-(l.code + 1)) >> 1;
+                    float *lb = &out.leaf_boxes[static_cast<size_t>(i) * 8];
+                    for (int a = 0; a < 6; ++a) lb[a] = l.box[a];
+                    const rt_sphere &s = d.spheres[i];
+                    double e = eps[static_cast<size_t>(i)];
+                    for (int a = 0; a < 3; ++a) e = std::max(e, 8.0 * 5.9604645e-8 * (std::fabs(double(s.center.e[a])) + s.radius));
+                    const float ef = static_cast<float>(e * (1.0 + 1e-6));
+                    for (int a = 0; a < 3; ++a) {
+                        l.box[2 * a] = std::nextafterf(l.box[2 * a] - ef, -INFINITY);
+                        l.box[2 * a + 1] = std::nextafterf(l.box[2 * a + 1] + ef, INFINITY);
+                    }
+                }
+                g.ok = true;
+            }
+        }
+        g.reason = why;
+        if (!g.ok) { g.large.clear(); g.num_small = 0; }
+    }
+
     // ---- traversal tree
     std::vector<BuildNode> bnodes;
     if (leaves.empty()) {
         out.root = kTraversalDone;
-    } else if (mode == TreeMode::Sah || d.nodes[0].left < 0) {
+    } else if (mode == TreeMode::Sah || mode == TreeMode::Guarded || d.nodes[0].left < 0) {
         SahBuilder b(leaves);
         float rb[6];
         out.root = b.build(0, static_cast<int>(leaves.size()), rb);

@@ -46,9 +46,30 @@ struct Packed {
     int32_t root = kTraversalDone; // node code of the root (leaf code when the scene has one primitive)
     int32_t num_internal = 0;
     int32_t max_depth = 0;         // longest root→leaf path in internal nodes = traversal stack bound
+    // Guarded near-first walk (TreeMode::Guarded): `nodes` then is an SAH tree over
+    // leaf boxes INFLATED by a per-sphere margin, and the kernel sends every sample whose result
+    // could depend on the visit order to the exact reference-order walk.  guard.ok == false (with
+    // a reason) → the scene is not eligible and only the reference-order walk may be used.
+    struct Guard {
+        bool ok = false;
+        std::string reason;
+        float center[3] = {0, 0, 0};   // centre of the "small sphere" cluster (class S)
+        float d0_sq = 0;               // origins farther than this from the centre get the far-origin test
+        float cluster_radius = 0;      // class S spheres lie within this distance of the centre
+        float box[6] = {0, 0, 0, 0, 0, 0};   // their bounding box (x.min x.max y.min y.max z.min z.max)
+        float far_k = 0;               // far-origin inflation of that box: far_k * (|o - centre| + cluster_radius)^2
+        int32_t num_small = 0;
+        // class L spheres (margin valid for any origin on a scene surface): centre, reach — the camera
+        // origin must be within `reach` of each, checked per render on the host
+        std::vector<float> large;      // 4 per sphere: centre xyz, reach
+    } guard;
+    std::vector<float> leaf_boxes;     // 8 floats per sphere: the caller's exact leaf box (+2 pad), for the final check
 };
 
-enum class TreeMode { Reference, Sah };
+enum class TreeMode { Reference, Sah, Guarded };
+
+// Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2.
+constexpr float kGuardGamma = 8.0f * 5.9604645e-8f;
 
 // Returns "" on success, else a message (→ RT_ERR_INVALID_ARG).
 std::string pack_scene(const rt_scene_desc &desc, TreeMode mode, Packed &out);

@@ -40,13 +40,18 @@ constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr int kMaxPasses = 1024;        // >= 64 samples per pass
 constexpr int kTimedPasses = 64;        // trace launches individually timed per call
 
-// Traversal mode.  "threaded" (default): the caller's tree in the reference's own visit order —
-// results equal the reference's even where they depend on visit order.  "ordered": SAH child-pair
-// tree, near child first — fewer box tests, identical results except for rays where a primitive's
-// computed hit lies in front of its own leaf box (see DESIGN.md "Traversal order").
-bool threaded_mode() {
+// Counter block of a scene handle (uint32 words): work counters of the trace launches, of the exact
+// re-walk launches, the flagged-sample counts (one each per pass), then 16 developer words.
+constexpr int kQueueWork = 0, kQueueRework = kMaxPasses, kQueueFlag = 2 * kMaxPasses, kQueueStats = 3 * kMaxPasses;
+constexpr int kQueueWords = 3 * kMaxPasses + 16;
+
+// Traversal.  "threaded": the caller's tree in the reference's own visit order — the result is the
+// reference's by construction.  "guarded" (default where the scene is eligible): near-first walk of
+// an SAH tree over inflated leaf boxes; every sample whose result could depend on the visit order
+// is flagged and re-walked in threaded mode, so the frame is the same.
+bool threaded_forced() {
     const char *v = getenv("RTP_TRAVERSAL");
-    return !(v && std::string(v) == "ordered");
+    return v && std::string(v) == "threaded";
 }
 
 }  // namespace
@@ -58,14 +63,19 @@ struct rt_scene {
     float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
-    uint32_t *queue = nullptr;      // kMaxPasses work counters + 16 developer-stat words
+    uint32_t *queue = nullptr;      // counter block, see kQueue*
     float4 *slab = nullptr;         // per-sample radiance workspace of one pass, grown on demand
     size_t slab_float4s = 0;
+    rtaccel::Packed::Guard guard;   // guarded-walk eligibility and parameters
+    float4 *leaf_boxes = nullptr;   // exact leaf box per sphere (final check of the guarded walk)
+    uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
+    size_t flag_cap = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> pass_events;   // pairs around each trace launch (first kTimedPasses passes)
     int timed_passes = 0;
     rt_timing last{};
+    int last_passes = 0;
     bool timed = false;
     int num_cus = 0;
 };
@@ -137,15 +147,20 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.queue = sc->queue;
     if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 pixels per call");
     P.total_work = (uint32_t)P.local_rows * (uint32_t)P.width * 64u;      // upper bound; set per pass in rt_render
-    P.stats = sc->queue + kMaxPasses;
+    P.stats = sc->queue + kQueueStats;
     {
         const uint64_t pixels = (uint64_t)P.local_rows * (uint64_t)P.width;
         if (!make_magic((uint32_t)P.width, pixels + 1, P.magic_width) ||
             !make_magic((uint32_t)P.band_rows, (uint64_t)P.local_rows + 1, P.magic_band))
             return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");
     }
-    P.stack_levels = sc->tree_depth + 1;      // ordered traversal: one LDS stack entry per tree level at most
-    if (P.stack_levels < 2) P.stack_levels = 2;
+    P.stack_levels = 0;
+    P.leaf_boxes = sc->leaf_boxes;
+    std::memcpy(P.g_center, sc->guard.center, 12);
+    P.g_d0sq = sc->guard.d0_sq;
+    P.g_rs = sc->guard.cluster_radius;
+    P.g_fark = sc->guard.far_k;
+    std::memcpy(P.g_box, sc->guard.box, 24);
     P.k_inner = env_int("RTP_K_INNER", 24);
     P.k_shade = env_int("RTP_K_SHADE", 48);
     return RT_OK;
@@ -171,9 +186,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARG, "null argument");
     *out_scene = nullptr;
     rtaccel::Packed pk;
-    const char *tree = getenv("RTP_TREE");
-    const rtaccel::TreeMode mode = (tree && std::string(tree) == "ref") ? rtaccel::TreeMode::Reference : rtaccel::TreeMode::Sah;
-    const std::string err = rtaccel::pack_scene(*desc, mode, pk);
+    const std::string err = rtaccel::pack_scene(*desc, rtaccel::TreeMode::Guarded, pk);
     if (!err.empty()) return fail(RT_ERR_INVALID_ARG, err);
 
     int n = 0;
@@ -197,7 +210,9 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if ((st = upload(pk.sphere_mat, (void **)&sc->sphere_mat)) != RT_OK) return bail(st);
     if ((st = upload(pk.tex_data, (void **)&sc->tex_data)) != RT_OK) return bail(st);
     if ((st = upload(pk.tex_info, (void **)&sc->tex_info)) != RT_OK) return bail(st);
-    if (hipMalloc((void **)&sc->queue, (kMaxPasses + 16) * 4) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"));
+    if ((st = upload(pk.leaf_boxes, (void **)&sc->leaf_boxes)) != RT_OK) return bail(st);
+    sc->guard = pk.guard;
+    if (hipMalloc((void **)&sc->queue, kQueueWords * 4) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"));
     if (hipEventCreate(&sc->ev_start) != hipSuccess || hipEventCreate(&sc->ev_stop) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
     sc->num_internal = pk.num_internal;
@@ -216,6 +231,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->xnodes);
     (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
+    (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->flag_list);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
@@ -254,32 +270,65 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         return RT_OK;
     }
 
-    const bool threaded = threaded_mode();
     const uint32_t waves = rtk::kBlock / rtk::kWave;
-    if (threaded) P.stack_levels = 0;
-    const uint32_t stack_bytes = waves * (uint32_t)P.stack_levels * rtk::kWave * 4u + waves * 8u;   // + per-wave pixel ranges
-    const uint64_t node_f4 = threaded ? ((uint64_t)P.num_tnodes + 1) * 2 : (uint64_t)P.num_internal * 4;
-    const uint64_t scene_bytes = (node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
-                                  ((uint64_t)P.num_spheres + 3) / 4) * 16;
-    const bool in_lds = !env_int("RTP_NO_LDS_SCENE", 0) && scene_bytes + stack_bytes <= kLdsLimit;
-    // big scene, reference-order walk: the top of the tree (explicit-link records [0, num_top)) is staged in LDS
-    if (in_lds || !threaded || env_int("RTP_NO_TREELET", 0)) P.num_top = 0;
-    const uint32_t treelet_bytes = (uint32_t)P.num_top * 32u;
-    // workgroups per CU: what the register budget admits (RTP_MIN_WAVES waves per SIMD), unless two
-    // LDS-resident scene copies do not fit next to each other
-    int wgs_per_cu = env_int("RTP_WGS_PER_CU", 0);
-    if (wgs_per_cu <= 0) {
-        wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
-        const uint64_t per_wg = in_lds ? scene_bytes + stack_bytes : stack_bytes + treelet_bytes;
-        while (wgs_per_cu > 1 && (uint64_t)wgs_per_cu * per_wg > kLdsLimit) --wgs_per_cu;
+    const uint32_t pool_bytes = waves * 8u;                  // per-wave reserved work range
+    const uint64_t prim_f4 = (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
+                             ((uint64_t)P.num_spheres + 3) / 4;
+
+    // ---- exact (threaded) walk: launch shape
+    struct Shape { bool in_lds; uint32_t lds_bytes; int wgs_per_cu; int32_t stack_levels; int32_t num_top; };
+    Shape exact{};
+    {
+        const uint64_t scene_bytes = (((uint64_t)P.num_tnodes + 1) * 2 + prim_f4) * 16;
+        exact.in_lds = !env_int("RTP_NO_LDS_SCENE", 0) && scene_bytes + pool_bytes <= kLdsLimit;
+        // big scene: the top of the tree (explicit-link records [0, num_top)) is staged in LDS
+        exact.num_top = (exact.in_lds || env_int("RTP_NO_TREELET", 0)) ? 0 : P.num_top;
+        const uint64_t per_wg = exact.in_lds ? scene_bytes + pool_bytes : pool_bytes + (uint64_t)exact.num_top * 32u;
+        // workgroups per CU: what the register budget admits (RTP_MIN_WAVES waves per SIMD), unless that
+        // many LDS-resident scene copies do not fit next to each other
+        exact.wgs_per_cu = env_int("RTP_WGS_PER_CU", 0);
+        if (exact.wgs_per_cu <= 0) {
+            exact.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
+            while (exact.wgs_per_cu > 1 && (uint64_t)exact.wgs_per_cu * per_wg > kLdsLimit) --exact.wgs_per_cu;
+        }
+        if (exact.wgs_per_cu < 1) exact.wgs_per_cu = 1;
+        exact.lds_bytes = (uint32_t)per_wg;
     }
-    if (wgs_per_cu < 1) wgs_per_cu = 1;
-    const uint32_t lds_bytes = (uint32_t)(in_lds ? scene_bytes + stack_bytes : stack_bytes + treelet_bytes);
-    if (lds_bytes > kLdsLimit) return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack");
-    int wgs = sc->num_cus * wgs_per_cu;
-    const uint32_t max_wgs = (uint32_t)(((uint64_t)P.local_rows * P.width * (P.spp < 64 ? P.spp : 64) + rtk::kBlock - 1) / rtk::kBlock);
-    if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
-    if (wgs < 1) wgs = 1;
+
+    // ---- guarded near-first walk: only for eligible scenes that fit LDS with a useful stack
+    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0 && !env_int("RTP_NO_LDS_SCENE", 0);
+    Shape fast{};
+    if (guarded) {
+        // class L spheres: the camera must lie within the reach their margin was computed for
+        for (size_t k = 0; k + 3 < sc->guard.large.size() && guarded; k += 4) {
+            const float *q = &sc->guard.large[k];
+            const double dx = (double)cam->origin.e[0] - q[0], dy = (double)cam->origin.e[1] - q[1], dz = (double)cam->origin.e[2] - q[2];
+            if (!(dx * dx + dy * dy + dz * dz <= (double)q[3] * q[3])) guarded = false;
+        }
+    }
+    if (guarded) {
+        const uint64_t scene_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;
+        const int32_t want = sc->tree_depth + 1 > 2 ? sc->tree_depth + 1 : 2;       // never overflows
+        const uint32_t per_level = rtk::kBlock * 4u;
+        auto levels_for = [&](int wgs_per_cu) -> int32_t {
+            const uint64_t budget = kLdsLimit / (uint64_t)wgs_per_cu;
+            if (scene_bytes + pool_bytes >= budget) return 0;
+            const int64_t fit = (int64_t)((budget - scene_bytes - pool_bytes) / per_level);
+            return (int32_t)(fit < want ? fit : want);
+        };
+        fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
+        fast.stack_levels = levels_for(fast.wgs_per_cu);
+        const int32_t min_levels = want < 4 ? want : 4;          // a shorter stack flags too many rays
+        while (fast.wgs_per_cu > 1 && fast.stack_levels < min_levels) fast.stack_levels = levels_for(--fast.wgs_per_cu);
+        if (const int forced = env_int("RTP_STACK_LEVELS", 0)) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
+        if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
+        fast.in_lds = true;
+        fast.lds_bytes = (uint32_t)(scene_bytes + pool_bytes + (uint64_t)fast.stack_levels * per_level);
+        if (const int w = env_int("RTP_WGS_PER_CU", 0)) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
+    }
+    bool use_queue = false;
+    if (const char *kq = getenv("RTP_KERNEL")) use_queue = std::string(kq) == "queue";
+    if (use_queue) guarded = false;
 
     // Samples per pass: as many as the slab budget admits (default 20 GiB of the 288 GB, RTP_SLAB_GIB),
     // at least 64, and few enough for the 32-bit work index and its reciprocal-multiply division.
@@ -319,14 +368,41 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     P.num_pixels = num_pixels;
     const int passes = (P.spp + pass_size - 1) / pass_size;
     if (passes > kMaxPasses) return fail(RT_ERR_UNSUPPORTED, "samples_per_pixel above 65536");
+    if (guarded) {
+        // flagged-sample list: a quarter of a pass's samples (a fuller list means "re-walk everything")
+        const size_t cap = need / 4 + 65536;
+        if (sc->flag_cap < cap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(sc->flag_list);
+            sc->flag_list = nullptr;
+            sc->flag_cap = 0;
+            HIP_TRY(hipMalloc((void **)&sc->flag_list, cap * sizeof(uint32_t)));
+            sc->flag_cap = cap;
+        }
+    }
 
-    HIP_TRY(hipMemsetAsync(sc->queue, 0, (kMaxPasses + 16) * 4, stream));
+    const Shape &main_shape = guarded ? fast : exact;
+    const uint32_t max_wgs = (uint32_t)(((uint64_t)num_pixels * (P.spp < 64 ? P.spp : 64) + rtk::kBlock - 1) / rtk::kBlock);
+    auto grid_for = [&](const Shape &sh) {
+        int wgs = sc->num_cus * sh.wgs_per_cu;
+        if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
+        return wgs < 1 ? 1 : wgs;
+    };
+    int wgs = grid_for(main_shape);
+
+    HIP_TRY(hipMemsetAsync(sc->queue, 0, kQueueWords * 4, stream));
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
-    auto launch = [&](auto kernel) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    auto launch = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(wgs), dim3(rtk::kBlock), lds_bytes, stream, P);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kBlock), lds, stream, KP);
         return hipGetLastError();
+    };
+    auto launch_exact = [&](rtk::KParams &KP, int grid) -> hipError_t {
+        KP.stack_levels = 0;
+        KP.num_top = exact.num_top;
+        if (exact.in_lds) return launch(rtk::render_kernel<true, true>, KP, grid, exact.lds_bytes);
+        return launch(rtk::render_kernel<false, true>, KP, grid, exact.lds_bytes);
     };
     while ((int)sc->pass_events.size() < 2 * (passes < kTimedPasses ? passes : kTimedPasses)) {
         hipEvent_t e;
@@ -334,16 +410,14 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         sc->pass_events.push_back(e);
     }
     sc->timed_passes = 0;
-    // RTP_KERNEL=queue: T-waves/S-waves with LDS queues (rt_kernel_queue.hip.inc), threaded + LDS-resident scenes only
-    bool use_queue = false;
+    // RTP_KERNEL=queue: T-waves/S-waves with LDS queues (rt_kernel_queue.hip.inc), exact walk + LDS-resident scenes only
     uint32_t q_lds = 0;
-    if (const char *kq = getenv("RTP_KERNEL")) use_queue = std::string(kq) == "queue";
-    if (use_queue && threaded && in_lds) {
+    if (use_queue && exact.in_lds) {
         P.q_s_waves = env_int("RTP_Q_SWAVES", 4);
         P.q_k_refill = env_int("RTP_Q_KREFILL", 16);
         P.q_k_busy = env_int("RTP_Q_KBUSY", 0);
         P.q_k_leaf = env_int("RTP_Q_KLEAF", 24);
-        const uint64_t base_f4 = node_f4 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + ((uint64_t)P.num_spheres + 3) / 4;
+        const uint64_t base_f4 = ((uint64_t)P.num_tnodes + 1) * 2 + (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + ((uint64_t)P.num_spheres + 3) / 4;
         const uint64_t mat_bytes = (uint64_t)P.num_materials * 48;
         uint32_t slots = (uint32_t)env_int("RTP_Q_SLOTS", 1152);
         auto lds_for = [&](uint32_t n, bool mats) {
@@ -376,15 +450,30 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
         if (!make_magic((uint32_t)P.pass_count, (uint64_t)P.total_work + 64, P.magic_count))
             return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");
-        P.queue = sc->queue + pass;
+        P.queue = sc->queue + kQueueWork + pass;
+        P.work_list = nullptr;
         if (use_queue) {
+            P.stack_levels = 0;
             HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel_q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds));
             hipLaunchKernelGGL(rtk::render_kernel_q<true>, dim3(wgs), dim3(rtk::kQBlock), q_lds, stream, P);
             HIP_TRY(hipGetLastError());
-        } else if (in_lds && threaded) HIP_TRY(launch(rtk::render_kernel<true, true>));
-        else if (in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>));
-        else if (threaded) HIP_TRY(launch(rtk::render_kernel<false, true>));
-        else HIP_TRY(launch(rtk::render_kernel<false, false>));
+        } else if (guarded) {
+            // near-first walk; samples it cannot vouch for go to the list …
+            P.stack_levels = fast.stack_levels;
+            P.flag_list = sc->flag_list;
+            P.flag_count = sc->queue + kQueueFlag + pass;
+            P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
+            HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
+            // … and are walked again in the reference's order, overwriting their slab entries
+            rtk::KParams R = P;
+            R.queue = sc->queue + kQueueRework + pass;
+            R.work_list = sc->flag_list;
+            R.work_count = sc->queue + kQueueFlag + pass;
+            R.work_cap = P.flag_cap;
+            HIP_TRY(launch_exact(R, grid_for(exact)));
+        } else {
+            HIP_TRY(launch_exact(P, wgs));
+        }
         if (timed_pass) { HIP_TRY(hipEventRecord(sc->pass_events[2 * pass + 1], stream)); sc->timed_passes = pass + 1; }
         // … then added to the pixel sums strictly in sample order
         hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 255) / 256), dim3(256), 0, stream, d_fb_sum,
@@ -396,9 +485,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last = rt_timing{};
     sc->last.num_workgroups = (uint32_t)wgs;
     sc->last.workgroup_size = use_queue ? rtk::kQBlock : rtk::kBlock;
-    sc->last.lds_bytes = use_queue ? q_lds : lds_bytes;
-    sc->last.scene_in_lds = in_lds ? 1u : 0u;
+    sc->last.lds_bytes = use_queue ? q_lds : main_shape.lds_bytes;
+    sc->last.scene_in_lds = main_shape.in_lds ? 1u : 0u;
     sc->last.trace_launches = (uint32_t)passes;
+    sc->last.guarded = guarded ? 1u : 0u;
+    sc->last_passes = passes;
     if (sync) return rt_last_timing(sc, timing);
     if (timing) *timing = sc->last;
     return RT_OK;
@@ -418,8 +509,15 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
         // passes beyond the individually timed ones are priced at the mean of the timed ones
         if (sc->timed_passes > 0) sum *= (float)sc->last.trace_launches / (float)sc->timed_passes;
         sc->last.trace_ms = sum;
+        if (sc->last.guarded) {
+            std::vector<uint32_t> counts((size_t)sc->last_passes);
+            HIP_TRY(hipMemcpy(counts.data(), sc->queue + kQueueFlag, counts.size() * 4, hipMemcpyDeviceToHost));
+            uint64_t total = 0;
+            for (uint32_t c : counts) total += c;
+            sc->last.flagged_samples = total;
+        }
         uint32_t abort_code = 0;
-        HIP_TRY(hipMemcpy(&abort_code, sc->queue + kMaxPasses + 15, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&abort_code, sc->queue + kQueueStats + 15, 4, hipMemcpyDeviceToHost));
         if (abort_code != 0) return fail(RT_ERR_HIP, "render_kernel_q aborted (queue protocol timeout, code " + std::to_string(abort_code) + ")");
     }
     if (timing) *timing = sc->last;
@@ -430,7 +528,7 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
 rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[12]) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, sc->queue + kMaxPasses, 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, sc->queue + kQueueStats, 48, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -477,14 +575,7 @@ rt_status rt_trace_samples(rt_scene *sc, const rt_camera_data *cam, int32_t n, c
     }
     if (hipMemcpy(d_ijs, ijs, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(RT_ERR_HIP, "hipMemcpy H2D failed"); }
     P.probe_ijs = d_ijs; P.probe_rad = d_rad; P.probe_rays = d_rays; P.probe_seed = d_seed; P.probe_n = n;
-    const uint32_t lds = 4u * (uint32_t)P.stack_levels * rtk::kWave * 4u;
-    if (lds > kLdsLimit) { cleanup(); return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack"); }
-    if (threaded_mode()) {
-        hipLaunchKernelGGL(rtk::probe_kernel<true>, dim3((n + 255) / 256), dim3(256), lds, 0, P);
-    } else {
-        (void)hipFuncSetAttribute((const void *)rtk::probe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(rtk::probe_kernel<false>, dim3((n + 255) / 256), dim3(256), lds, 0, P);
-    }
+    hipLaunchKernelGGL(rtk::probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, P);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(radiance, d_rad, (size_t)n * 12, hipMemcpyDeviceToHost);
@@ -517,15 +608,8 @@ rt_status rt_closest_hits(rt_scene *sc, int32_t n, const float *origins, const f
     if (e == hipSuccess) e = hipMemcpy(d_d, directions, n3, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_t, 0, n1);
     if (e == hipSuccess) e = hipMemset(d_prim, 0xff, n1);
-    const uint32_t lds = 4u * (uint32_t)P.stack_levels * rtk::kWave * 4u;
-    if (e == hipSuccess && lds > kLdsLimit) { cleanup(); return fail(RT_ERR_UNSUPPORTED, "BVH too deep for the LDS traversal stack"); }
     if (e == hipSuccess) {
-        if (threaded_mode()) {
-            hipLaunchKernelGGL(rtk::closest_hit_kernel<true>, dim3((n + 255) / 256), dim3(256), lds, 0, P, d_o, d_d, n, d_hit, d_t, d_prim);
-        } else {
-            (void)hipFuncSetAttribute((const void *)rtk::closest_hit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(rtk::closest_hit_kernel<false>, dim3((n + 255) / 256), dim3(256), lds, 0, P, d_o, d_d, n, d_hit, d_t, d_prim);
-        }
+        hipLaunchKernelGGL(rtk::closest_hit_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, P, d_o, d_d, n, d_hit, d_t, d_prim);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();

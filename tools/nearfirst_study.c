@@ -1,0 +1,260 @@
+/* Developer study (CPU): how many node visits would a per-octant near-first order of the CALLER'S
+ * tree save over the reference's left-first order, how often would the conservative pruning band
+ * flag a ray for an exact re-walk, and is the result identical for the unflagged rays?
+ * Build: gcc -O2 -ffp-contract=off -std=gnu11 -Iinclude tools/nearfirst_study.c \
+ *            -Lray-tracing-practice_amd -lrtp_host -Wl,-rpath,$PWD/ray-tracing-practice_amd -lm -lpthread -o /tmp/nf_study
+ */
+#include <stdio.h>
+#include <stdlib.h>
+struct rt_scene_desc;
+struct ray_s;
+static void study_ray(const void *sc, const void *r);
+#define ORC_STUDY_HOOK(sc, r) study_ray(sc, r)
+#include "../oracle/rt_oracle.c"
+#include "../ray-tracing-practice_amd/host/rtp_host.h"
+
+static unsigned long long n_rays, v_ref, v_oct, v_oct_band, n_flag, n_flag_prune, n_flag_incons, n_mismatch, n_mismatch_unflagged, lt_ref, lt_oct;
+static float g_delta = 1.0f / 1024;
+static int *g_axis;      /* split axis guessed per inner node */
+
+/* box test returning the entry distance too */
+static inline int aabb_hit_e(const float box[6], const ray *r, float tmin, float tmax, float *enter) {
+    for (int a = 0; a < 3; a++) {
+        float invD = 1 / r->d.e[a];
+        float orig = r->o.e[a];
+        float t1 = (box[2 * a] - orig) * invD;
+        float t2 = (box[2 * a + 1] - orig) * invD;
+        if (invD < 0) { float tmp = t1; t1 = t2; t2 = tmp; }
+        if (t1 > tmin) tmin = t1;
+        if (t2 < tmax) tmax = t2;
+        if (tmax <= tmin) { *enter = tmin; return 0; }
+    }
+    *enter = tmin;
+    return 1;
+}
+
+struct snode_s; static void *g_s_any; static void sah_ray(const ray *r, float c_ref, int prim_ref);
+static void study_ray(const void *scv, const void *rv) {
+    const rt_scene_desc *sc = (const rt_scene_desc *)scv;
+    const ray *r = (const ray *)rv;
+    const rt_bvh_node *nodes = sc->nodes;
+    n_rays++;
+    /* reference walk */
+    float c_ref = 1e30f; int p_ref = -1;
+    {
+        int stack[64], sp = 0; stack[sp++] = 0;
+        while (sp > 0) {
+            const rt_bvh_node *n = &nodes[stack[--sp]];
+            v_ref++;
+            if (!aabb_hit(n->box, r, 0.001f, c_ref)) continue;
+            if (n->left < 0) {
+                hitrec tmp; lt_ref++;
+                if (hit_sphere(r, 0.001f, c_ref, &tmp, &sc->spheres[n->right])) { c_ref = tmp.t; p_ref = (int)(n - nodes); }
+            } else { stack[sp++] = n->right; stack[sp++] = n->left; }
+        }
+    }
+    /* octant order walk with pruning band */
+    float c = 1e30f; int p = -1; int flagged_prune = 0, flagged_incons = 0;
+    {
+        int stack[64], sp = 0; stack[sp++] = 0;
+        while (sp > 0) {
+            const int idx = stack[--sp];
+            const rt_bvh_node *n = &nodes[idx];
+            v_oct++;
+            float enter;
+            /* exact test with the running closest decides the walk */
+            const int hit = aabb_hit_e(n->box, r, 0.001f, c, &enter);
+            if (!hit) {
+                /* would the box have been entered with a slightly larger closest?  then a primitive whose computed
+                 * root lies in front of its own box could hide below it */
+                if (c < 1e30f) {
+                    float e2;
+                    if (aabb_hit_e(n->box, r, 0.001f, c * (1.0f + g_delta), &e2)) flagged_prune = 1;
+                }
+                continue;
+            }
+            if (n->left < 0) {
+                hitrec tmp; lt_oct++;
+                /* contains(): root <= closest is accepted; on an exact tie the reference keeps the LAST visited = larger index */
+                if (hit_sphere(r, 0.001f, c, &tmp, &sc->spheres[n->right])) {
+                    if (tmp.t < c || idx > p) { if (tmp.t <= enter) flagged_incons = 1; c = tmp.t; p = idx; }
+                }
+            } else {
+                const int a = g_axis[idx];
+                const int left_first = r->d.e[a] >= 0;
+                if (left_first) { stack[sp++] = n->right; stack[sp++] = n->left; }
+                else { stack[sp++] = n->left; stack[sp++] = n->right; }
+            }
+        }
+    }
+    if (g_s_any) sah_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
+    const int flagged = flagged_prune | flagged_incons;
+    n_flag += flagged; n_flag_prune += flagged_prune; n_flag_incons += flagged_incons;
+    const int mismatch = (p != p_ref) || (p >= 0 && c != c_ref);
+    n_mismatch += mismatch;
+    if (mismatch && !flagged) n_mismatch_unflagged++;
+}
+
+/* ---- own SAH tree over the same leaf boxes, walked near-first by entry distance ---- */
+typedef struct { float box[6]; int left, right, prim; } snode;
+static snode *g_s; static int g_sn;
+static const rt_scene_desc *g_scn;
+static float *g_pbox;  /* per sphere leaf box from the caller's tree, inflated by eps_q */
+static float *g_rbox;  /* the caller's exact leaf boxes */
+static float g_sc[3], g_d0 = 64.0f, g_gamma = 8 * 5.96e-8f;
+static int g_cmp_axis;
+static int cmp_prim(const void *a, const void *b) {
+    const float *A = g_pbox + 6 * *(const int *)a, *B = g_pbox + 6 * *(const int *)b;
+    const float ca = A[2 * g_cmp_axis] + A[2 * g_cmp_axis + 1], cb = B[2 * g_cmp_axis] + B[2 * g_cmp_axis + 1];
+    return ca < cb ? -1 : ca > cb;
+}
+static float area(const float *b) { const float x = b[1] - b[0], y = b[3] - b[2], z = b[5] - b[4]; return x * y + y * z + z * x; }
+static void grow(float *b, const float *q) { for (int a = 0; a < 3; a++) { if (q[2*a] < b[2*a]) b[2*a] = q[2*a]; if (q[2*a+1] > b[2*a+1]) b[2*a+1] = q[2*a+1]; } }
+static int sah_build(int *ids, int n) {
+    const int me = g_sn++;
+    float bb[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};
+    for (int i = 0; i < n; i++) grow(bb, g_pbox + 6 * ids[i]);
+    memcpy(g_s[me].box, bb, sizeof bb);
+    if (n == 1) { g_s[me].left = -1; g_s[me].prim = ids[0]; return me; }
+    float best = 1e30f; int best_axis = 0, best_k = n / 2;
+    int *tmp = malloc(n * sizeof(int)); float *ra = malloc(n * sizeof(float));
+    for (int a = 0; a < 3; a++) {
+        memcpy(tmp, ids, n * sizeof(int)); g_cmp_axis = a; qsort(tmp, n, sizeof(int), cmp_prim);
+        float rb[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};
+        for (int i = n - 1; i > 0; i--) { grow(rb, g_pbox + 6 * tmp[i]); ra[i] = area(rb); }
+        float lb[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};
+        for (int k = 1; k < n; k++) {
+            grow(lb, g_pbox + 6 * tmp[k - 1]);
+            const float cost = area(lb) * k + ra[k] * (n - k);
+            if (cost < best) { best = cost; best_axis = a; best_k = k; }
+        }
+    }
+    g_cmp_axis = best_axis; qsort(ids, n, sizeof(int), cmp_prim);
+    free(tmp); free(ra);
+    const int l = sah_build(ids, best_k), r = sah_build(ids + best_k, n - best_k);
+    g_s[me].left = l; g_s[me].right = r;
+    return me;
+}
+static unsigned long long v_sah, lt_sah, n_sah_flag, n_sah_mismatch, n_sah_mismatch_unflagged, v_sah_pairs, n_tie, n_incons_final, n_overflow;
+static unsigned long long depth_hist[40];
+static double g_max_ratio;       /* max observed (enter' - t) / bound over accepted hits */
+static float g_beta = 16 * 5.96e-8f;
+static unsigned long long n_far, n_far_flag;
+static float g_bs[6];
+static int g_levels = 64;
+static float *g_rmax;            /* per SAH node: largest radius below */
+static void sah_ray(const ray *r, float c_ref, int prim_ref) {
+    float c = 1e30f; int p = -1; int flag = 0; float p_enter = 0;
+    struct { int idx; float enter; } stack[64]; int sp = 0, maxsp = 0;
+    const float inv_len = 1.0f / sqrtf(lensq(r->d));
+    const float bd = g_beta * inv_len;
+    { float dd = 0; for (int a = 0; a < 3; a++) dd += (r->o.e[a] - g_sc[a]) * (r->o.e[a] - g_sc[a]); if (dd > g_d0 * g_d0) { n_far++; float e; if (dd > 800.0f * 800.0f || aabb_hit_e(g_bs, r, 0.001f, 1e30f, &e)) { flag = 1; n_far_flag++; if (n_far_flag % 3000 == 1) fprintf(stderr, "far: o (%.2f %.2f %.3f) d (%.3f %.3f %.4f) e %.3f\n", r->o.e[0], r->o.e[1], r->o.e[2], r->d.e[0], r->d.e[1], r->d.e[2], e); } } }
+    int cur = 0; float cur_enter = 0.001f; int have = 1;
+    v_sah++;
+    { float e0; if (!aabb_hit_e(g_s[0].box, r, 0.001f, 1e30f, &e0)) have = 0; cur_enter = e0; }
+    while (have) {
+        const snode *n = &g_s[cur];
+        if (n->left < 0) {
+            hitrec tmp; lt_sah++; const float c_before = c;
+            if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[n->prim])) {
+                if (tmp.t == c && p >= 0) { flag = 1; n_tie++; }
+                c = tmp.t; p = n->prim; p_enter = cur_enter;
+                double dep = 0; { const float *rb = g_rbox + 6 * n->prim; for (int a = 0; a < 3; a++) { const double x = (double)r->o.e[a] + (double)tmp.t * r->d.e[a]; if (rb[2*a] - x > dep) dep = rb[2*a] - x; if (x - rb[2*a+1] > dep) dep = x - rb[2*a+1]; } }
+                const double bound = (double)(g_rbox[6 * n->prim] - g_pbox[6 * n->prim]);
+                if (dep > 0 && !flag) { const double ratio = dep / bound; if (ratio > g_max_ratio) { g_max_ratio = ratio; fprintf(stderr, "dep %.3g eps %.3g t %.5g r %.3g\n", dep, bound, tmp.t, g_scn->spheres[n->prim].radius); } }
+                if (0) { const double ratio = ((double)cur_enter - tmp.t) / bound; if (ratio > g_max_ratio) { g_max_ratio = ratio; fprintf(stderr, "worst: t %.6g enter %.6g c_before %.6g r %.4g |d| %.4g o (%.3f %.3f %.3f) d (%.4f %.4f %.4f) center (%.3f %.3f %.3f)\n", tmp.t, cur_enter, c_before, g_scn->spheres[n->prim].radius, 1.0f / inv_len, r->o.e[0], r->o.e[1], r->o.e[2], r->d.e[0], r->d.e[1], r->d.e[2], g_scn->spheres[n->prim].center.e[0], g_scn->spheres[n->prim].center.e[1], g_scn->spheres[n->prim].center.e[2]); } }
+            }
+        } else {
+            float el, er; v_sah += 2; v_sah_pairs++;
+            const float cl = c + g_beta * c, cr = cl; (void)bd;
+            const int hl = aabb_hit_e(g_s[n->left].box, r, 0.001f, cl, &el), hr = aabb_hit_e(g_s[n->right].box, r, 0.001f, cr, &er);
+            if (hl && hr) {
+                const int lf = el <= er;
+                if (sp >= g_levels) { flag = 1; n_overflow++; }
+                else { stack[sp].idx = lf ? n->right : n->left; stack[sp++].enter = lf ? er : el; if (sp > maxsp) maxsp = sp; }
+                cur = lf ? n->left : n->right; cur_enter = lf ? el : er; continue;
+            } else if (hl) { cur = n->left; cur_enter = el; continue; }
+            else if (hr) { cur = n->right; cur_enter = er; continue; }
+        }
+        if (sp == 0) break;
+        sp--; cur = stack[sp].idx; cur_enter = stack[sp].enter;
+    }
+    depth_hist[maxsp]++;
+    if (p >= 0) { float e; const int h = aabb_hit_e(g_rbox + 6 * p, r, 0.001f, 1e30f, &e); if (!h || c <= e) { flag = 1; n_incons_final++; } }
+    (void)p_enter;
+    n_sah_flag += flag;
+    const int mm = (p != prim_ref) || (p >= 0 && c != c_ref);
+    n_sah_mismatch += mm; if (mm && !flag) n_sah_mismatch_unflagged++;
+}
+static float fill_rmax(int i) {
+    if (g_s[i].left < 0) return g_rmax[i] = g_scn->spheres[g_s[i].prim].radius;
+    const float a = fill_rmax(g_s[i].left), b = fill_rmax(g_s[i].right);
+    return g_rmax[i] = a > b ? a : b;
+}
+
+int main(int argc, char **argv) {
+    const int half = argc > 1 ? atoi(argv[1]) : 11;
+    const int W = argc > 2 ? atoi(argv[2]) : 192, H = argc > 3 ? atoi(argv[3]) : 108, spp = argc > 4 ? atoi(argv[4]) : 8;
+    if (argc > 5) g_beta = (float)atof(argv[5]);
+    if (argc > 6) g_levels = atoi(argv[6]);
+    rtp_host_scene *hs = rtp_host_scene_rtiow(12345u, half, 0, 0);
+    rt_scene_desc sc; rtp_host_scene_desc(hs, &sc);
+    rt_camera_data cam;
+    const float eye[3] = {13, 3, 2}, at[3] = {0, 0, 0}, bg[3] = {0.7f, 0.8f, 1.0f};
+    rtp_host_make_camera(W, H, 20.0f, eye, at, bg, spp, 50, &cam);
+    g_axis = calloc(sc.num_nodes, sizeof(int));
+    for (int i = 0; i < sc.num_nodes; i++) {
+        const rt_bvh_node *n = &sc.nodes[i];
+        if (n->left < 0) continue;
+        const float *L = sc.nodes[n->left].box, *R = sc.nodes[n->right].box;
+        float best = -1e30f; int ax = 0;
+        for (int a = 0; a < 3; a++) {
+            const float sep = (R[2 * a] + R[2 * a + 1]) - (L[2 * a] + L[2 * a + 1]);
+            const float ext = n->box[2 * a + 1] - n->box[2 * a];
+            const float s = sep / (ext > 0 ? ext : 1);
+            if (s > best) { best = s; ax = a; }
+        }
+        g_axis[i] = ax;
+    }
+    g_scn = &sc;
+    g_pbox = malloc(sizeof(float) * 6 * sc.num_spheres);
+    for (int i = 0; i < sc.num_nodes; i++) if (sc.nodes[i].left < 0) memcpy(g_pbox + 6 * sc.nodes[i].right, sc.nodes[i].box, 24);
+    g_rbox = malloc(sizeof(float) * 6 * sc.num_spheres);
+    memcpy(g_rbox, g_pbox, sizeof(float) * 6 * sc.num_spheres);
+    {   /* guard centre: centroid box of the spheres with radius below 10x the median-ish (here: < 100) */
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = 0; i < sc.num_spheres; i++) if (sc.spheres[i].radius < 100) for (int a = 0; a < 3; a++) {
+            if (sc.spheres[i].center.e[a] < lo[a]) lo[a] = sc.spheres[i].center.e[a];
+            if (sc.spheres[i].center.e[a] > hi[a]) hi[a] = sc.spheres[i].center.e[a]; }
+        for (int a = 0; a < 3; a++) g_sc[a] = 0.5f * (lo[a] + hi[a]);
+        { float rm = 0; for (int i = 0; i < sc.num_spheres; i++) if (sc.spheres[i].radius < 100 && sc.spheres[i].radius > rm) rm = sc.spheres[i].radius;
+          for (int a = 0; a < 3; a++) { g_bs[2 * a] = lo[a] - rm - 1.0f; g_bs[2 * a + 1] = hi[a] + rm + 1.0f; } }
+        if (argc > 7) g_d0 = (float)atof(argv[7]);
+        for (int i = 0; i < sc.num_spheres; i++) {
+            float dc = 0; for (int a = 0; a < 3; a++) dc += (sc.spheres[i].center.e[a] - g_sc[a]) * (sc.spheres[i].center.e[a] - g_sc[a]);
+            const float reach = sqrtf(dc) + g_d0 + sc.spheres[i].radius;
+            const float eps = g_gamma * reach * reach / (2 * sc.spheres[i].radius);
+            for (int a = 0; a < 3; a++) { g_pbox[6 * i + 2 * a] -= eps; g_pbox[6 * i + 2 * a + 1] += eps; }
+            if (i < 3 || i == sc.num_spheres - 1) printf("sphere %d r %.3g eps %.3g\n", i, sc.spheres[i].radius, eps);
+        }
+    }
+    int *ids = malloc(sizeof(int) * sc.num_spheres);
+    for (int i = 0; i < sc.num_spheres; i++) ids[i] = i;
+    snode *sn = malloc(sizeof(snode) * 2 * sc.num_spheres);
+    g_s = sn; g_sn = 0; sah_build(ids, sc.num_spheres); g_rmax = malloc(sizeof(float) * g_sn); fill_rmax(0); g_s_any = sn;
+    float *fb = malloc((size_t)W * H * 3 * sizeof(float));
+    orc_render(&sc, &cam, 0, H, fb, 1, NULL);
+    printf("scene half=%d nodes=%d  %dx%d spp=%d delta=%g\n", half, sc.num_nodes, W, H, spp, g_delta);
+    printf("rays %llu  visits/ray ref %.2f  octant-order %.2f (%.1f%%)  leaf tests/ray ref %.2f oct %.2f\n", n_rays, (double)v_ref / n_rays,
+           (double)v_oct / n_rays, 100.0 * v_oct / v_ref, (double)lt_ref / n_rays, (double)lt_oct / n_rays);
+    printf("flagged %.4f%% (prune band %.4f%%, inconsistent accept %.6f%%)  mismatches %llu, of which unflagged %llu\n", 100.0 * n_flag / n_rays,
+           100.0 * n_flag_prune / n_rays, 100.0 * n_flag_incons / n_rays, n_mismatch, n_mismatch_unflagged);
+    printf("SAH tree, near-first, inflated pruning beta=%g levels=%d: box tests/ray %.2f (pair steps %.2f)  leaf tests/ray %.2f\n", g_beta, g_levels,
+           (double)v_sah / n_rays, (double)v_sah_pairs / n_rays, (double)lt_sah / n_rays);
+    printf("  flagged %.4f%% (ties %llu, inconsistent final %llu, overflow %llu)  mismatches %llu (unflagged %llu)  far origins %llu (flagged %llu)  max departure/eps %.3g\n",
+           100.0 * n_sah_flag / n_rays, n_tie, n_incons_final, n_overflow, n_sah_mismatch, n_sah_mismatch_unflagged, n_far, n_far_flag, g_max_ratio);
+    printf("  max pending-stack depth per ray:");
+    for (int i = 0; i < 24; i++) if (depth_hist[i]) printf(" %d:%.4f%%", i, 100.0 * depth_hist[i] / n_rays);
+    printf("\n");
+    return 0;
+}
