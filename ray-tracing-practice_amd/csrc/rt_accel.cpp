@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -348,13 +349,26 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                     for (int a = 0; a < 6; ++a) lb[a] = l.box[a];
                     const rt_sphere &s = d.spheres[i];
                     double e = eps[static_cast<size_t>(i)];
-                    for (int a = 0; a < 3; ++a) e = std::max(e, 8.0 * 5.9604645e-8 * (std::fabs(double(s.center.e[a])) + s.radius));
+                    // floor: the rounding of the box tests themselves (coordinates of the box and of any
+                    // ray origin in the scene, a few ulps each)
+                    for (int a = 0; a < 3; ++a) e = std::max(e, 32.0 * 5.9604645e-8 * (std::fabs(double(s.center.e[a])) + s.radius + std::fabs(C[a]) + 1.25 * r_all));
                     const float ef = static_cast<float>(e * (1.0 + 1e-6));
                     for (int a = 0; a < 3; ++a) {
                         l.box[2 * a] = std::nextafterf(l.box[2 * a] - ef, -INFINITY);
                         l.box[2 * a + 1] = std::nextafterf(l.box[2 * a + 1] + ef, INFINITY);
                     }
                 }
+                // leaf boxes that are exactly fl(c - r), fl(c + r) (what the reference's builder makes) can be
+                // recomputed in the kernel from the sphere record: no table
+                bool derivable = true;
+                for (int i = 0; i < d.num_spheres && derivable; ++i) {
+                    if (leaf_of[static_cast<size_t>(i)] < 0) continue;
+                    const rt_sphere &s = d.spheres[i];
+                    const float *lb = &out.leaf_boxes[static_cast<size_t>(i) * 8];
+                    for (int a = 0; a < 3; ++a)
+                        if (lb[2 * a] != s.center.e[a] - s.radius || lb[2 * a + 1] != s.center.e[a] + s.radius) derivable = false;
+                }
+                if (derivable && !getenv("RTP_GUARD_TABLE")) out.leaf_boxes.clear();
                 g.ok = true;
             }
         }

@@ -34,6 +34,21 @@ static inline int aabb_hit_e(const float box[6], const ray *r, float tmin, float
 }
 
 struct snode_s; static void *g_s_any; static void sah_ray(const ray *r, float c_ref, int prim_ref);
+static int g_fused = 0;
+static inline int aabb_hit_fused(const float box[6], const ray *r, float tmin0, float tmax0, float *enter) {
+    float nr[3], fr[3];
+    for (int a = 0; a < 3; a++) {
+        float inv = 1 / r->d.e[a];
+        inv = fminf(fmaxf(inv, -1e18f), 1e18f);
+        const float noi = -(r->o.e[a] * inv);
+        const float ta = fmaf(box[2 * a], inv, noi), tb = fmaf(box[2 * a + 1], inv, noi);
+        nr[a] = fminf(ta, tb); fr[a] = fmaxf(ta, tb);
+    }
+    const float tmin = fmaxf(fmaxf(nr[0], nr[1]), fmaxf(nr[2], tmin0));
+    const float tmax = fminf(fminf(fr[0], fr[1]), fminf(fr[2], tmax0));
+    *enter = tmin;
+    return tmax > tmin;
+}
 static void study_ray(const void *scv, const void *rv) {
     const rt_scene_desc *sc = (const rt_scene_desc *)scv;
     const ray *r = (const ray *)rv;
@@ -167,7 +182,7 @@ static void sah_ray(const ray *r, float c_ref, int prim_ref) {
         } else {
             float el, er; v_sah += 2; v_sah_pairs++;
             const float cl = c + g_beta * c, cr = cl; (void)bd;
-            const int hl = aabb_hit_e(g_s[n->left].box, r, 0.001f, cl, &el), hr = aabb_hit_e(g_s[n->right].box, r, 0.001f, cr, &er);
+            const int hl = g_fused ? aabb_hit_fused(g_s[n->left].box, r, 0.001f, cl, &el) : aabb_hit_e(g_s[n->left].box, r, 0.001f, cl, &el), hr = g_fused ? aabb_hit_fused(g_s[n->right].box, r, 0.001f, cr, &er) : aabb_hit_e(g_s[n->right].box, r, 0.001f, cr, &er);
             if (hl && hr) {
                 const int lf = el <= er;
                 if (sp >= g_levels) { flag = 1; n_overflow++; }
@@ -184,7 +199,7 @@ static void sah_ray(const ray *r, float c_ref, int prim_ref) {
     (void)p_enter;
     n_sah_flag += flag;
     const int mm = (p != prim_ref) || (p >= 0 && c != c_ref);
-    n_sah_mismatch += mm; if (mm && !flag) n_sah_mismatch_unflagged++;
+    n_sah_mismatch += mm; if (mm && !flag) { n_sah_mismatch_unflagged++; fprintf(stderr, "UNFLAGGED MISMATCH: ref prim %d t %.9g  got prim %d t %.9g  o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", prim_ref, c_ref, p, c, r->o.e[0], r->o.e[1], r->o.e[2], r->d.e[0], r->d.e[1], r->d.e[2]); }
 }
 static float fill_rmax(int i) {
     if (g_s[i].left < 0) return g_rmax[i] = g_scn->spheres[g_s[i].prim].radius;
@@ -197,6 +212,7 @@ int main(int argc, char **argv) {
     const int W = argc > 2 ? atoi(argv[2]) : 192, H = argc > 3 ? atoi(argv[3]) : 108, spp = argc > 4 ? atoi(argv[4]) : 8;
     if (argc > 5) g_beta = (float)atof(argv[5]);
     if (argc > 6) g_levels = atoi(argv[6]);
+    if (getenv("FUSED")) g_fused = 1;
     rtp_host_scene *hs = rtp_host_scene_rtiow(12345u, half, 0, 0);
     rt_scene_desc sc; rtp_host_scene_desc(hs, &sc);
     rt_camera_data cam;
