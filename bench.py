@@ -123,7 +123,7 @@ def main():
     fb = torch.zeros((local_rows, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
 
-    kernel_ms, trace_ms, launches = [], [], []
+    kernel_ms, trace_ms, launches, guarded, flagged = [], [], [], [], []
 
     def step(record):
         dev.render(cam, fb.data_ptr(), shard=shard, stream=stream, sync=False)
@@ -137,6 +137,8 @@ def main():
             kernel_ms.append(t.kernel_ms)
             trace_ms.append(t.trace_ms)
             launches.append(t.trace_launches)
+            guarded.append(t.guarded)
+            flagged.append(t.flagged_samples)
         return frame
 
     def fence():
@@ -171,7 +173,8 @@ def main():
             "config": {"workload": f"S-rtiow random-sphere scene (486 spheres, 971 BVH nodes, seed 12345), {WIDTH}x{HEIGHT}, "
                                    f"{args.spp} spp, {DEPTH} bounces, background (0.7,0.8,1.0)",
                        "parallelism": f"row-band shard x{world} + 1 gather" if world > 1 else "single GPU",
-                       "traversal": os.environ.get("RTP_TRAVERSAL", "threaded")},
+                       "traversal": ("guarded near-first walk + exact re-walk of flagged samples" if guarded and guarded[0]
+                                     else "reference-order (threaded) walk")},
         }
         base, st = (None, None)
         if world > 1 and os.environ.get("RTP_BENCH_CHECK"):
@@ -213,7 +216,10 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "rtk::render_kernel<true,true>", "launches_per_step": n_launch, "launch_ms": round(launch_ms, 3),
+            "kernel": "rtk::render_kernel<true,false> (+ exact re-walk render_kernel<true,true>)" if guarded and guarded[0]
+                      else "rtk::render_kernel<true,true>",
+            "launches_per_step": n_launch, "launch_ms": round(launch_ms, 3),
+            "flagged_sample_fraction": round(float(np.mean(flagged)) / max(local_samples, 1), 6) if flagged else None,
             "step_kernels_ms": round(k_ms, 3),
             "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
             "valu_side_from_committed_pmc": valu,

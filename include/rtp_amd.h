@@ -161,6 +161,12 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene);
 /* Replaces destroy_scene_arrays / destroy_texture_resources (src/main.cu:235-246,322-344). */
 rt_status rt_scene_destroy(rt_scene *scene);
 
+/* Which closest-hit walk rt_render uses for this scene.  "" = the guarded near-first walk with an
+ * exact re-walk of flagged samples (sphere-only scenes whose tables fit LDS); otherwise the reason
+ * the scene only gets the reference-order walk (e.g. "scene has planes").  Results are the same
+ * bits either way; this is a diagnostic.  The string lives as long as the scene. */
+const char *rt_scene_guard_reason(const rt_scene *scene);
+
 /* Number of rows rt_render writes for (image_height, shard). */
 int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard);
 

@@ -312,7 +312,6 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                     for (int a = 0; a < 3; ++a) { slo[a] = fminf(slo[a], s.center.e[a]); shi[a] = fmaxf(shi[a], s.center.e[a]); }
                 }
             }
-            if (g.large.size() > 4 * 64) why = "too many large spheres for the per-render camera check";
             if (why.empty() && g.num_small > 0) {
                 const double sc[3] = {0.5 * (double(slo[0]) + shi[0]), 0.5 * (double(slo[1]) + shi[1]), 0.5 * (double(slo[2]) + shi[2])};
                 double rs = 0;

@@ -239,6 +239,11 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     return RT_OK;
 }
 
+const char *rt_scene_guard_reason(const rt_scene *sc) {
+    if (!sc) return "null scene";
+    return sc->guard.ok ? "" : sc->guard.reason.c_str();
+}
+
 int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard) {
     if (image_height <= 0) return 0;
     if (!shard || shard->num_parts <= 1 || shard->band_rows <= 0) return image_height;
@@ -525,10 +530,10 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
 }
 
 // Developer hook (not part of the ABI header): raw counters of an RTP_STATS build.
-rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[12]) {
+rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[16]) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, sc->queue + kQueueStats, 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, sc->queue + kQueueStats, 60, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

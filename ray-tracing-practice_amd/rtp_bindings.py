@@ -74,7 +74,7 @@ assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
 
 # Every symbol include/rtp_amd.h declares (tests check that the library exports all of them).
 RTP_AMD_SYMBOLS = [
-    "rt_set_device", "rt_scene_create", "rt_scene_destroy", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
+    "rt_set_device", "rt_scene_create", "rt_scene_destroy", "rt_scene_guard_reason", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
     "rt_last_timing",
     "rt_render_to_host", "rt_trace_samples", "rt_closest_hits", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
     "rt_get_last_error_string", "rt_version_string",
@@ -124,6 +124,8 @@ def amd_lib():
         lib.rt_set_device.argtypes = [C.c_int32]
         lib.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         lib.rt_scene_destroy.argtypes = [C.c_void_p]
+        lib.rt_scene_guard_reason.argtypes = [C.c_void_p]
+        lib.rt_scene_guard_reason.restype = C.c_char_p
         lib.rt_shard_rows.argtypes = [C.c_int32, C.POINTER(Shard)]
         lib.rt_shard_rows.restype = C.c_int32
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p, C.c_void_p,
@@ -278,6 +280,10 @@ class DeviceScene:
         _check(amd_lib().rt_trace_samples(self._h, C.byref(cam), n, ijs.ctypes.data, rad.ctypes.data, rays.ctypes.data,
                                           seeds.ctypes.data), "rt_trace_samples")
         return rad, rays, seeds
+
+    def guard_reason(self):
+        """'' when rt_render may use the guarded near-first walk, else why not."""
+        return amd_lib().rt_scene_guard_reason(self._h).decode()
 
     def closest_hits(self, origins, directions):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -2,6 +2,7 @@
 // with AddressSanitizer + UBSan by tests/test_accel_native.py.  It links the host mirror's scene
 // builders to get real inputs, so the sanitizers also sweep the config parser, the polyhedra
 // builders, the BVH builder and the JPEG/PPM loaders' callers.
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -144,6 +145,64 @@ int main() {
         rtaccel::Packed pk;
         CHECK(rtaccel::pack_scene(empty.desc(), rtaccel::TreeMode::Sah, pk).empty());
         CHECK(pk.num_tnodes == 0 && pk.root == rtaccel::kTraversalDone);
+    }
+    {   // guarded-walk parameters
+        rtp::RtiowOptions o;
+        o.half_extent = 11;
+        rtp::HostScene hs;
+        rtp::build_rtiow_scene(o, hs);
+        rtaccel::Packed pk;
+        CHECK(rtaccel::pack_scene(hs.desc(), rtaccel::TreeMode::Guarded, pk).empty());
+        CHECK(pk.guard.ok && pk.guard.reason.empty());
+        CHECK(pk.guard.num_small == 485 && pk.guard.large.size() == 4);        // the ground sphere is the one "large" sphere
+        CHECK(pk.leaf_boxes.empty());                                          // leaf boxes are fl(c -/+ r): derived in the kernel
+        CHECK(pk.guard.d0_sq > 4 * pk.guard.cluster_radius * pk.guard.cluster_radius * 0.99f);
+        // every child box of the walk's tree holds the sphere below it with the documented margin
+        size_t leaves_seen = 0;
+        for (int32_t k = 0; k < pk.num_internal; ++k)
+            for (int c = 0; c < 2; ++c) {
+                const float *n = &pk.nodes[(size_t)k * 16];
+                const int32_t code = ibits(n[12 + c]);
+                if (code >= 0) continue;
+                const int32_t idx = (-(code + 1)) >> 1;
+                const rt_sphere &sp = hs.spheres[(size_t)idx];
+                const float *lo = n + 6 * c, *hi = n + 6 * c + 3;
+                const double r = sp.radius;
+                // small spheres: gamma * reach^2 / (2 r) with reach = d0 + cluster radius (4 % of the smallest radius)
+                const double reach = std::sqrt((double)pk.guard.d0_sq) + pk.guard.cluster_radius;
+                const double margin = idx == 0 ? 1e-4 : 0.99 * rtaccel::kGuardGamma * reach * reach / (2 * r);
+                if (idx != 0 && r < 0.25) CHECK(margin > 0.035 * r);
+                for (int a = 0; a < 3; ++a) {
+                    CHECK(lo[a] <= sp.center.e[a] - r - margin && hi[a] >= sp.center.e[a] + r + margin);
+                    CHECK(lo[a] >= sp.center.e[a] - r - 0.1 * r && hi[a] <= sp.center.e[a] + r + 0.1 * r);   // and not absurdly more
+                }
+                ++leaves_seen;
+            }
+        CHECK(leaves_seen == hs.spheres.size());
+        // not eligible: planes; a sphere in two leaves; a leaf box that does not hold its sphere
+        rtp::HostScene with_plane;
+        o.textured_floor_quad = true;
+        o.texture_size = 8;
+        rtp::build_rtiow_scene(o, with_plane);
+        CHECK(rtaccel::pack_scene(with_plane.desc(), rtaccel::TreeMode::Guarded, pk).empty());
+        CHECK(!pk.guard.ok && pk.guard.reason == "scene has planes" && pk.num_tnodes > 0);
+        std::vector<rt_bvh_node> nodes(hs.nodes);
+        rt_scene_desc d = hs.desc();
+        d.nodes = nodes.data();
+        int first_leaf = -1, second_leaf = -1;
+        for (size_t k = 0; k < nodes.size(); ++k)
+            if (nodes[k].left < 0) { if (first_leaf < 0) first_leaf = (int)k; else if (second_leaf < 0) second_leaf = (int)k; }
+        const int32_t keep = nodes[(size_t)second_leaf].right;
+        nodes[(size_t)second_leaf].right = nodes[(size_t)first_leaf].right;
+        CHECK(rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk).empty() && !pk.guard.ok);
+        nodes[(size_t)second_leaf].right = keep;
+        nodes[(size_t)first_leaf].box[1] -= 0.05f;
+        CHECK(rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk).empty() && !pk.guard.ok);
+        // a caller's tree with padded leaf boxes is eligible, but then the exact boxes travel as a table
+        nodes = hs.nodes;
+        for (rt_bvh_node &n : nodes) { for (int a = 0; a < 3; ++a) { n.box[2 * a] -= 0.01f; n.box[2 * a + 1] += 0.01f; } }
+        CHECK(rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk).empty());
+        CHECK(pk.guard.ok && pk.leaf_boxes.size() == hs.spheres.size() * 8);
     }
     std::printf(failures ? "FAILED (%d)\n" : "all ok\n", failures);
     return failures ? 1 : 0;

@@ -340,26 +340,100 @@ def test_cli_frame_drivers_write_reference_bytes(test_config_text, golden, tmp_p
 
 
 def test_alternative_kernels_agree_with_default(rtiow):
-    """RTP_KERNEL=queue (T/S waves + LDS queues) must be bit-identical to the default kernel;
-    RTP_TRAVERSAL=ordered (near-first SAH walk) is allowed the order-dependent rays DESIGN.md §3
-    describes — tolerance: at least 99.99 % of the pixels bit-identical."""
+    """The exact walk alone (RTP_TRAVERSAL=threaded) and the experimental T/S-wave kernel
+    (RTP_KERNEL=queue) must give the bits of the default (guarded walk + exact re-walk)."""
     host, dev = rtiow
     cam = rb.rtiow_camera(320, 200, 8, 50)
-    want, _ = dev.render_to_host(cam)
+    want, t = dev.render_to_host(cam)
+    assert t.guarded == 1
     assert_same_frame(want, ob.render(host, cam, threads=8), "default kernel")
     try:
         os.environ["RTP_KERNEL"] = "queue"
         got, t = dev.render_to_host(cam)
-        assert t.workgroup_size == 1024
+        assert t.workgroup_size == 1024 and t.guarded == 0
         assert_same_frame(got, want, "queue kernel")
         del os.environ["RTP_KERNEL"]
-        os.environ["RTP_TRAVERSAL"] = "ordered"
-        got, _ = dev.render_to_host(cam)
-        same = (bits(got) == bits(want)).all(axis=-1)
-        assert same.mean() >= 0.9999, f"{(~same).sum()} pixels differ"
+        os.environ["RTP_TRAVERSAL"] = "threaded"
+        got, t = dev.render_to_host(cam)
+        assert t.guarded == 0 and t.flagged_samples == 0
+        assert_same_frame(got, want, "exact walk only")
     finally:
         os.environ.pop("RTP_KERNEL", None)
         os.environ.pop("RTP_TRAVERSAL", None)
+
+
+def test_guarded_walk_flags_and_rewalks(rtiow):
+    """The guarded near-first walk hands a small share of the samples (far origins, hits in front of
+    their own leaf box, a full stack) to the exact walk; with a 2-entry stack it hands over many
+    more — the frame is the oracle's either way."""
+    host, dev = rtiow
+    cam = rb.rtiow_camera(480, 270, 16, 50)
+    n = 480 * 270 * 16
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.scene_in_lds == 1
+    assert 0 < t.flagged_samples < 0.02 * n, t.flagged_samples
+    rows = ob.render(host, cam, row0=100, row1=140, threads=8)
+    assert_same_frame(fb[100:140], rows, "guarded walk")
+    try:
+        os.environ["RTP_STACK_LEVELS"] = "2"
+        fb2, t2 = dev.render_to_host(cam)
+        assert t2.guarded == 1 and t2.flagged_samples > 4 * t.flagged_samples
+        assert_same_frame(fb2, fb, "2-entry stack")
+    finally:
+        os.environ.pop("RTP_STACK_LEVELS", None)
+
+
+def test_guarded_walk_far_camera_and_ties():
+    """Cases the guards exist for.  (a) A camera far outside the distance the box inflation was
+    sized for: every primary ray takes the far-origin test.  (b) Coincident and overlapping
+    spheres: exact ties of the hit distance, which the reference resolves by visit order."""
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0)
+    cam = rb.make_camera(160, 90, 3.0, (400.0, 90.0, 60.0), (0, 0, 0), (0.7, 0.8, 1.0), 4, 50)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.flagged_samples > 0
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "far camera")
+
+    mats = [_material(0, albedo=(0.8, 0.3, 0.3)), _material(0, albedo=(0.2, 0.9, 0.3)), _material(1, albedo=(0.9, 0.9, 0.9), fuzz=0.1),
+            _material(2, ir=1.5)]
+    spheres = np.array([[0, 0, 0, 1, 0], [0, 0, 0, 1, 1],                      # the same sphere twice, two materials
+                        [2, 0, 0, 1, 2], [2, 0, 0, 1, 3],                      # again, metal and glass
+                        [0, 2.5, 0, 1, 1], [0, 2.5, 0.75, 1, 0],               # overlapping
+                        [0, 0, -101, 100, 0]], dtype=np.float32)
+    host = rb.HostScene.from_arrays(spheres, np.zeros((0, 11), np.float32), mats)
+    dev = rb.DeviceScene(host, device=0)
+    cam = rb.make_camera(200, 120, 40.0, (6, 5, 2.5), (0.7, 0.8, 0), (0.6, 0.7, 0.9), 6, 20)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.flagged_samples > 0          # the ties
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "coincident spheres")
+
+
+def test_guarded_walk_random_sphere_scenes():
+    """Sphere-only random scenes (the ones eligible for the guarded walk): radii over three decades,
+    overlaps, a huge ground sphere in half of them, cameras inside and far outside the cluster."""
+    rng = np.random.default_rng(77)
+    for trial in range(12):
+        n = int(rng.integers(2, 300))
+        mats = [_material(int(rng.integers(0, 4)), albedo=rng.uniform(0.1, 1.0, 3), fuzz=float(rng.uniform(0, 0.7)),
+                          ir=float(rng.uniform(1.1, 2.0)), absorption=rng.uniform(0, 0.6, 3) if rng.random() < 0.5 else (0, 0, 0),
+                          emit=rng.uniform(0.5, 3.0, 3)) for _ in range(6)]
+        spheres = np.zeros((n, 5), dtype=np.float32)
+        spread = float(rng.choice([3.0, 10.0, 40.0]))
+        spheres[:, :3] = rng.uniform(-spread, spread, (n, 3))
+        spheres[:, 3] = 10.0 ** rng.uniform(-2.0, 0.5, n)
+        spheres[:, 4] = rng.integers(0, len(mats), n)
+        if trial % 2 == 0:
+            spheres[0] = (0, 0, -1000 - spread, 1000, 0)
+        host = rb.HostScene.from_arrays(spheres, np.zeros((0, 11), np.float32), mats)
+        dev = rb.DeviceScene(host, device=0)
+        eye = rng.uniform(-spread, spread, 3) * (20.0 if trial % 5 == 4 else 1.0)
+        cam = rb.make_camera(int(rng.integers(40, 200)), int(rng.integers(30, 120)), float(rng.uniform(15, 90)), eye,
+                             rng.uniform(-1, 1, 3), rng.uniform(0, 1, 3), int(rng.integers(1, 6)), int(rng.integers(1, 40)))
+        fb, t = dev.render_to_host(cam)
+        assert dev.guard_reason() == ""
+        if trial % 5 != 4:      # (a camera beyond the reach of a large sphere's margin gets the exact walk for that call)
+            assert t.guarded == 1, f"trial {trial} not guarded"
+        assert_same_frame(fb, ob.render(host, cam, threads=8), f"sphere scene {trial}")
 
 
 def test_stress_scene_at_4k_rows():

@@ -14,8 +14,9 @@ print('cfg', {k:v for k,v in os.environ.items() if k.startswith('RTP_')}, 'best 
 import ctypes as C
 lib=rb.amd_lib()
 if os.environ.get('STATS'):
-    out=(C.c_uint32*12)()
+    out=(C.c_uint32*16)()
     lib.rt_debug_read_stats(ds._h, out)
+    print('  shade step split (kticks): shade() %d  store+next sample %d  begin_ray+guard (in shadephase) ' % (out[12], out[13]))
     names=['inner','leaf','shadephase','shade']
     ns=W*H*SPP
     for k,n in enumerate(names):

@@ -29,11 +29,21 @@ for name in ("fetch", "write", "valu", "wait"):
 shutil.copy(os.path.join(src, "bench_n1.json"), os.path.join(dst, "bench_n1.json"))
 
 
+# the dominant kernel: the render_kernel instantiation with the most time in the trace (with the guarded walk
+# a second instantiation, the exact re-walk of flagged samples, runs once per pass too)
+stats_rows = [r for r in csv.DictReader(open(os.path.join(dst, "bench_kernel_stats.csv"))) if "render_kernel" in r["Name"]]
+stats_rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+MAIN = stats_rows[0]["Name"]
+REWORK = stats_rows[1]["Name"] if len(stats_rows) > 1 else None
+
+
 def means(name):
     """{kernel kind: {counter: mean over launches}} and launch counts"""
     acc, cnt = {}, {}
     for r in csv.DictReader(open(os.path.join(dst, f"pmc_{name}.csv"))):
-        kind = "trace" if "render_kernel" in r["Kernel_Name"] else "accumulate" if "accumulate_kernel" in r["Kernel_Name"] else None
+        kn = r["Kernel_Name"]
+        kind = ("trace" if MAIN.startswith(kn) or kn.startswith(MAIN) else "rework" if "render_kernel" in kn
+                else "accumulate" if "accumulate_kernel" in kn else None)
         if kind is None:
             continue
         key = (kind, r["Counter_Name"])
@@ -51,12 +61,14 @@ traffic = {
             "--warmup 0 --no-cpu-baseline` (tools/profile_bench.sh); means over the trace launches of the frame; values in KiB as "
             "reported; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 reports half "
             f"of wide coalesced reads). Raw rows: profiles/{rnd}/pmc_fetch.csv, pmc_write.csv.",
+    "trace_kernel": MAIN,
     "trace_launches_per_frame": launches,
     "trace_kernel_fetch_kib": f[("trace", "FETCH_SIZE")],
     "trace_kernel_write_kib": w[("trace", "WRITE_SIZE")],
     "accumulate_kernel_fetch_kib": f[("accumulate", "FETCH_SIZE")],
     "accumulate_kernel_write_kib": w[("accumulate", "WRITE_SIZE")],
     "bytes_per_trace_launch": int((2 * f[("trace", "FETCH_SIZE")] + w[("trace", "WRITE_SIZE")]) * 1024),
+    "bytes_per_rework_launch": int((2 * f.get(("rework", "FETCH_SIZE"), 0) + w.get(("rework", "WRITE_SIZE"), 0)) * 1024),
     "bytes_per_accumulate_launch": int((2 * f[("accumulate", "FETCH_SIZE")] + w[("accumulate", "WRITE_SIZE")]) * 1024),
 }
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
