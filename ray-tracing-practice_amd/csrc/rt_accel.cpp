@@ -245,23 +245,22 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
         }
     }
 
-    // ---- guarded mode: eligibility, per-sphere inflation, exact leaf boxes for the final check
+    // ---- guarded mode: eligibility, per-primitive inflation, exact leaf boxes for the final check
     if (mode == TreeMode::Guarded) {
         Packed::Guard &g = out.guard;
         std::string why;
-        std::vector<int32_t> leaf_of(static_cast<size_t>(d.num_spheres), -1);
-        if (d.num_planes > 0) why = "scene has planes";
-        else if (leaves.empty()) why = "no primitives";
-        else if (d.num_spheres >= (1 << 24)) why = "too many spheres";
+        const double u = 5.9604645e-8;       // 2^-24
+        std::vector<int32_t> leaf_of_sphere(static_cast<size_t>(d.num_spheres), -1), leaf_of_plane(static_cast<size_t>(d.num_planes), -1);
+        if (leaves.empty()) why = "no primitives";
+        else if (d.num_spheres >= (1 << 24) || d.num_planes >= (1 << 24)) why = "too many primitives";
         for (int k = 0; k < d.num_nodes && why.empty(); ++k) {
             if (!reachable[static_cast<size_t>(k)]) continue;
             const rt_bvh_node &n = d.nodes[k];
             if (depth[static_cast<size_t>(k)] + 2 > 32) why = "tree deeper than hit_bvh's stack";       // the reference prunes silently there
             for (int a = 0; a < 6 && why.empty(); ++a) if (!std::isfinite(n.box[a])) why = "non-finite box";
-            if (n.left < 0) {
-                if (n.type != 0) { why = "leaf that is not a sphere"; break; }
-                if (leaf_of[static_cast<size_t>(n.right)] >= 0) { why = "sphere referenced by two leaves"; break; }
-                leaf_of[static_cast<size_t>(n.right)] = k;
+            if (n.left < 0 && n.type == 0) {
+                if (leaf_of_sphere[static_cast<size_t>(n.right)] >= 0) { why = "sphere referenced by two leaves"; break; }
+                leaf_of_sphere[static_cast<size_t>(n.right)] = k;
                 const rt_sphere &s = d.spheres[n.right];
                 if (!(s.radius > 0) || !std::isfinite(s.radius)) { why = "sphere radius not positive"; break; }
                 for (int a = 0; a < 3; ++a) {
@@ -271,6 +270,23 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                     const float tol = 4.0f * 5.9604645e-8f * (fabsf(c) + s.radius);
                     if (n.box[2 * a] > c - s.radius + tol || n.box[2 * a + 1] < c + s.radius - tol) why = "leaf box does not contain its sphere";
                 }
+            } else if (n.left < 0 && n.type == 1) {
+                if (leaf_of_plane[static_cast<size_t>(n.right)] >= 0) { why = "plane referenced by two leaves"; break; }
+                leaf_of_plane[static_cast<size_t>(n.right)] = k;
+                const rt_plane &pl = d.planes[n.right];
+                if (pl.type != RT_PLANE_QUAD && pl.type != RT_PLANE_ELLIPSE && pl.type != RT_PLANE_TRIANGLE) { why = "plane of unknown type"; break; }
+                // accepted hits lie (up to rounding) inside base + a u + b v, a, b in [0,1] (a + b <= 1 for a
+                // triangle): the leaf box must hold those corners
+                const int corners = pl.type == RT_PLANE_TRIANGLE ? 3 : 4;
+                for (int c = 0; c < corners && why.empty(); ++c)
+                    for (int a = 0; a < 3; ++a) {
+                        const double x = double(pl.base.e[a]) + ((c & 1) ? double(pl.u.e[a]) : 0.0) + ((c & 2) ? double(pl.v.e[a]) : 0.0);
+                        if (!std::isfinite(x)) { why = "non-finite plane"; break; }
+                        const double tol = 8.0 * u * (std::fabs(double(pl.base.e[a])) + std::fabs(double(pl.u.e[a])) + std::fabs(double(pl.v.e[a])));
+                        if (n.box[2 * a] > x + tol || n.box[2 * a + 1] < x - tol) { why = "leaf box does not contain its plane"; break; }
+                    }
+            } else if (n.left < 0) {
+                why = "leaf of unknown type";
             } else {
                 for (int child : {n.left, n.right}) {
                     const rt_bvh_node &c = d.nodes[child];
@@ -280,7 +296,7 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
             }
         }
         if (why.empty()) {
-            // bounding sphere of everything a path can start from (surfaces of all spheres)
+            // bounding sphere (C, r_all) of everything a path can start from: the surfaces of all primitives
             float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (const LeafRef &l : leaves)
                 for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], l.box[2 * a]); hi[a] = fmaxf(hi[a], l.box[2 * a + 1]); }
@@ -288,35 +304,51 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
             auto dist = [](const double a[3], const float b[3]) {
                 return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
             };
-            double r_all = 0;
-            for (int i = 0; i < d.num_spheres; ++i)
-                if (leaf_of[static_cast<size_t>(i)] >= 0) r_all = std::max(r_all, dist(C, d.spheres[i].center.e) + d.spheres[i].radius);
-            // class L: the margin for ANY origin on a scene surface stays below 5 % of the radius
+            double r_all = 0, coord_max = 0;
+            for (const LeafRef &l : leaves) {
+                double far2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const double e = std::max(std::fabs(l.box[2 * a] - C[a]), std::fabs(l.box[2 * a + 1] - C[a]));
+                    far2 += e * e;
+                    coord_max = std::max(coord_max, std::max(std::fabs(double(l.box[2 * a])), std::fabs(double(l.box[2 * a + 1]))));
+                }
+                r_all = std::max(r_all, std::sqrt(far2));
+            }
+            // ray origins: any point of a scene surface is within r_all of C; 25 % on top for the camera (checked per render)
+            const double origin_radius = 1.25 * r_all;
+            for (int a = 0; a < 3; ++a) g.origin_center[a] = static_cast<float>(C[a]);
+            g.origin_radius = static_cast<float>(origin_radius);
+            // floor of every margin: the rounding of the walk's own box tests and of o + t d (a few ulps of the
+            // coordinates of the box and of any ray origin)
+            const double eps_floor = 32.0 * u * (coord_max + std::fabs(C[0]) + std::fabs(C[1]) + std::fabs(C[2]) + origin_radius);
+            // planes: an accepted hit passed the interior test on the computed point itself, so it is in
+            // the primitive up to rounding — the floor, doubled, is the whole margin
+            const double eps_plane = 2.0 * eps_floor;
+            // spheres, class L ("large"): the margin for ANY admissible origin stays below 5 % of the radius
             std::vector<char> large(static_cast<size_t>(d.num_spheres), 0);
             std::vector<double> eps(static_cast<size_t>(d.num_spheres), 0.0);
             float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
             double r_min_small = INFINITY;
             for (int i = 0; i < d.num_spheres; ++i) {
-                if (leaf_of[static_cast<size_t>(i)] < 0) continue;
+                if (leaf_of_sphere[static_cast<size_t>(i)] < 0) continue;
                 const rt_sphere &s = d.spheres[i];
-                // any point of a scene surface is within r_all of C; 25 % on top for the camera (checked per render)
-                const double reach = 1.25 * (dist(C, s.center.e) + r_all);
+                const double reach = dist(C, s.center.e) + origin_radius;
                 const double e = double(kGuardGamma) * reach * reach / (2.0 * s.radius);
                 if (e <= 0.05 * s.radius) {
                     large[static_cast<size_t>(i)] = 1;
                     eps[static_cast<size_t>(i)] = e;
-                    g.large.insert(g.large.end(), {s.center.e[0], s.center.e[1], s.center.e[2], static_cast<float>(reach)});
+                    g.num_large++;
                 } else {
                     g.num_small++;
                     r_min_small = std::min(r_min_small, double(s.radius));
                     for (int a = 0; a < 3; ++a) { slo[a] = fminf(slo[a], s.center.e[a]); shi[a] = fmaxf(shi[a], s.center.e[a]); }
                 }
             }
-            if (why.empty() && g.num_small > 0) {
+            if (g.num_small > 0) {
                 const double sc[3] = {0.5 * (double(slo[0]) + shi[0]), 0.5 * (double(slo[1]) + shi[1]), 0.5 * (double(slo[2]) + shi[2])};
                 double rs = 0;
                 for (int i = 0; i < d.num_spheres; ++i)
-                    if (leaf_of[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
+                    if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
                         rs = std::max(rs, dist(sc, d.spheres[i].center.e) + d.spheres[i].radius);
                 // origins within d0 of the centre: margin 4 % of the smallest radius, but never less than the
                 // cluster itself (paths start on its surfaces)
@@ -324,55 +356,50 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                 if (reach < 2.0 * rs) reach = 2.0 * rs;
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)
-                    if (leaf_of[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
+                    if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
                         eps[static_cast<size_t>(i)] = double(kGuardGamma) * reach * reach / (2.0 * d.spheres[i].radius);
                 for (int a = 0; a < 3; ++a) g.center[a] = static_cast<float>(sc[a]);
                 g.d0_sq = static_cast<float>(d0 * d0 * (1.0 - 1e-6));
                 g.cluster_radius = static_cast<float>(rs * (1.0 + 1e-6));
                 g.far_k = static_cast<float>(double(kGuardGamma) / (2.0 * r_min_small) * (1.0 + 1e-6));
                 for (int i = 0; i < d.num_spheres; ++i) {
-                    if (leaf_of[static_cast<size_t>(i)] < 0 || large[static_cast<size_t>(i)]) continue;
-                    const float *b = d.nodes[leaf_of[static_cast<size_t>(i)]].box;
+                    if (leaf_of_sphere[static_cast<size_t>(i)] < 0 || large[static_cast<size_t>(i)]) continue;
+                    const float *b = d.nodes[leaf_of_sphere[static_cast<size_t>(i)]].box;
                     for (int a = 0; a < 3; ++a) { slo[a] = fminf(slo[a], b[2 * a]); shi[a] = fmaxf(shi[a], b[2 * a + 1]); }
                 }
                 for (int a = 0; a < 3; ++a) { g.box[2 * a] = slo[a]; g.box[2 * a + 1] = shi[a]; }
-            } else if (why.empty()) {
+            } else {
                 g.d0_sq = INFINITY;       // no small spheres: no far-origin test
             }
-            if (why.empty()) {
-                // inflate the leaf boxes the traversal tree is built from; keep the exact ones for the final check
-                out.leaf_boxes.assign(static_cast<size_t>(d.num_spheres) * 8, 0.0f);
-                for (LeafRef &l : leaves) {
-                    const int32_t i = (-(l.code + 1)) >> 1;
-                    float *lb = &out.leaf_boxes[static_cast<size_t>(i) * 8];
-                    for (int a = 0; a < 6; ++a) lb[a] = l.box[a];
-                    const rt_sphere &s = d.spheres[i];
-                    double e = eps[static_cast<size_t>(i)];
-                    // floor: the rounding of the box tests themselves (coordinates of the box and of any
-                    // ray origin in the scene, a few ulps each)
-                    for (int a = 0; a < 3; ++a) e = std::max(e, 32.0 * 5.9604645e-8 * (std::fabs(double(s.center.e[a])) + s.radius + std::fabs(C[a]) + 1.25 * r_all));
-                    const float ef = static_cast<float>(e * (1.0 + 1e-6));
-                    for (int a = 0; a < 3; ++a) {
-                        l.box[2 * a] = std::nextafterf(l.box[2 * a] - ef, -INFINITY);
-                        l.box[2 * a + 1] = std::nextafterf(l.box[2 * a + 1] + ef, INFINITY);
-                    }
+            // inflate the leaf boxes the traversal tree is built from; keep the exact ones for the final check
+            out.leaf_boxes.assign(static_cast<size_t>(d.num_spheres) * 8, 0.0f);
+            out.plane_leaf_boxes.assign(static_cast<size_t>(d.num_planes) * 8, 0.0f);
+            for (LeafRef &l : leaves) {
+                const int32_t code = -(l.code + 1);
+                const int32_t i = code >> 1;
+                float *lb = (code & 1) ? &out.plane_leaf_boxes[static_cast<size_t>(i) * 8] : &out.leaf_boxes[static_cast<size_t>(i) * 8];
+                for (int a = 0; a < 6; ++a) lb[a] = l.box[a];
+                const double e = (code & 1) ? eps_plane : std::max(eps[static_cast<size_t>(i)], eps_floor);
+                const float ef = static_cast<float>(e * (1.0 + 1e-6));
+                for (int a = 0; a < 3; ++a) {
+                    l.box[2 * a] = std::nextafterf(l.box[2 * a] - ef, -INFINITY);
+                    l.box[2 * a + 1] = std::nextafterf(l.box[2 * a + 1] + ef, INFINITY);
                 }
-                // leaf boxes that are exactly fl(c - r), fl(c + r) (what the reference's builder makes) can be
-                // recomputed in the kernel from the sphere record: no table
-                bool derivable = true;
-                for (int i = 0; i < d.num_spheres && derivable; ++i) {
-                    if (leaf_of[static_cast<size_t>(i)] < 0) continue;
-                    const rt_sphere &s = d.spheres[i];
-                    const float *lb = &out.leaf_boxes[static_cast<size_t>(i) * 8];
-                    for (int a = 0; a < 3; ++a)
-                        if (lb[2 * a] != s.center.e[a] - s.radius || lb[2 * a + 1] != s.center.e[a] + s.radius) derivable = false;
-                }
-                if (derivable && !getenv("RTP_GUARD_TABLE")) out.leaf_boxes.clear();
-                g.ok = true;
             }
+            // sphere leaf boxes that are exactly fl(c - r), fl(c + r) (what the reference's builder makes) can be
+            // recomputed in the kernel from the sphere record: no table
+            bool derivable = true;
+            for (int i = 0; i < d.num_spheres && derivable; ++i) {
+                if (leaf_of_sphere[static_cast<size_t>(i)] < 0) continue;
+                const rt_sphere &s = d.spheres[i];
+                const float *lb = &out.leaf_boxes[static_cast<size_t>(i) * 8];
+                for (int a = 0; a < 3; ++a)
+                    if (lb[2 * a] != s.center.e[a] - s.radius || lb[2 * a + 1] != s.center.e[a] + s.radius) derivable = false;
+            }
+            if (derivable && !getenv("RTP_GUARD_TABLE")) out.leaf_boxes.clear();
+            g.ok = true;
         }
         g.reason = why;
-        if (!g.ok) { g.large.clear(); g.num_small = 0; }
     }
 
     // ---- traversal tree

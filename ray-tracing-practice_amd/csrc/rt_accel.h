@@ -58,12 +58,15 @@ struct Packed {
         float cluster_radius = 0;      // class S spheres lie within this distance of the centre
         float box[6] = {0, 0, 0, 0, 0, 0};   // their bounding box (x.min x.max y.min y.max z.min z.max)
         float far_k = 0;               // far-origin inflation of that box: far_k * (|o - centre| + cluster_radius)^2
-        int32_t num_small = 0;
-        // class L spheres (margin valid for any origin on a scene surface): centre, reach — the camera
-        // origin must be within `reach` of each, checked per render on the host
-        std::vector<float> large;      // 4 per sphere: centre xyz, reach
+        int32_t num_small = 0, num_large = 0;
+        // every margin assumes ray origins within origin_radius of origin_center (all scene surfaces +
+        // 25 %): the camera position is checked against it per render
+        float origin_center[3] = {0, 0, 0};
+        float origin_radius = 0;
     } guard;
-    std::vector<float> leaf_boxes;     // 8 floats per sphere: the caller's exact leaf box (+2 pad), for the final check
+    std::vector<float> leaf_boxes;        // 8 floats per sphere: the caller's exact leaf box (+2 pad), for the final check
+                                          // (empty when every box is exactly fl(c -/+ r): the kernel recomputes it)
+    std::vector<float> plane_leaf_boxes;  // 8 floats per plane, same purpose
 };
 
 enum class TreeMode { Reference, Sah, Guarded };

@@ -67,7 +67,7 @@ struct rt_scene {
     float4 *slab = nullptr;         // per-sample radiance workspace of one pass, grown on demand
     size_t slab_float4s = 0;
     rtaccel::Packed::Guard guard;   // guarded-walk eligibility and parameters
-    float4 *leaf_boxes = nullptr;   // exact leaf box per sphere (final check of the guarded walk)
+    float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
@@ -156,6 +156,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     }
     P.stack_levels = 0;
     P.leaf_boxes = sc->leaf_boxes;
+    P.plane_leaf_boxes = sc->plane_leaf_boxes;
     std::memcpy(P.g_center, sc->guard.center, 12);
     P.g_d0sq = sc->guard.d0_sq;
     P.g_rs = sc->guard.cluster_radius;
@@ -211,6 +212,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if ((st = upload(pk.tex_data, (void **)&sc->tex_data)) != RT_OK) return bail(st);
     if ((st = upload(pk.tex_info, (void **)&sc->tex_info)) != RT_OK) return bail(st);
     if ((st = upload(pk.leaf_boxes, (void **)&sc->leaf_boxes)) != RT_OK) return bail(st);
+    if ((st = upload(pk.plane_leaf_boxes, (void **)&sc->plane_leaf_boxes)) != RT_OK) return bail(st);
     sc->guard = pk.guard;
     if (hipMalloc((void **)&sc->queue, kQueueWords * 4) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"));
     if (hipEventCreate(&sc->ev_start) != hipSuccess || hipEventCreate(&sc->ev_stop) != hipSuccess)
@@ -231,7 +233,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->xnodes);
     (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
-    (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->flag_list);
+    (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
@@ -301,34 +303,41 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     }
 
     // ---- guarded near-first walk: only for eligible scenes that fit LDS with a useful stack
-    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0 && !env_int("RTP_NO_LDS_SCENE", 0);
+    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0;
     Shape fast{};
     if (guarded) {
-        // class L spheres: the camera must lie within the reach their margin was computed for
-        for (size_t k = 0; k + 3 < sc->guard.large.size() && guarded; k += 4) {
-            const float *q = &sc->guard.large[k];
-            const double dx = (double)cam->origin.e[0] - q[0], dy = (double)cam->origin.e[1] - q[1], dz = (double)cam->origin.e[2] - q[2];
-            if (!(dx * dx + dy * dy + dz * dz <= (double)q[3] * q[3])) guarded = false;
-        }
+        // the margins were sized for ray origins within origin_radius of origin_center: so must the camera be
+        const float *q = sc->guard.origin_center;
+        const double dx = (double)cam->origin.e[0] - q[0], dy = (double)cam->origin.e[1] - q[1], dz = (double)cam->origin.e[2] - q[2];
+        if (!(dx * dx + dy * dy + dz * dz <= (double)sc->guard.origin_radius * sc->guard.origin_radius)) guarded = false;
     }
     if (guarded) {
-        const uint64_t scene_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;
+        const uint64_t table_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;
         const int32_t want = sc->tree_depth + 1 > 2 ? sc->tree_depth + 1 : 2;       // never overflows
         const uint32_t per_level = rtk::kBlock * 4u;
-        auto levels_for = [&](int wgs_per_cu) -> int32_t {
+        // tables in LDS when they leave room for a useful stack at full occupancy; else they are read
+        // through L1/L2 and LDS holds only the stacks
+        auto levels_for = [&](uint64_t scene_bytes, int wgs_per_cu) -> int32_t {
             const uint64_t budget = kLdsLimit / (uint64_t)wgs_per_cu;
             if (scene_bytes + pool_bytes >= budget) return 0;
             const int64_t fit = (int64_t)((budget - scene_bytes - pool_bytes) / per_level);
             return (int32_t)(fit < want ? fit : want);
         };
-        fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
-        fast.stack_levels = levels_for(fast.wgs_per_cu);
         const int32_t min_levels = want < 4 ? want : 4;          // a shorter stack flags too many rays
-        while (fast.wgs_per_cu > 1 && fast.stack_levels < min_levels) fast.stack_levels = levels_for(--fast.wgs_per_cu);
+        fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
+        fast.in_lds = !env_int("RTP_NO_LDS_SCENE", 0);
+        if (fast.in_lds) {
+            fast.stack_levels = levels_for(table_bytes, fast.wgs_per_cu);
+            while (fast.wgs_per_cu > 1 && fast.stack_levels < min_levels) fast.stack_levels = levels_for(table_bytes, --fast.wgs_per_cu);
+            if (fast.stack_levels < min_levels) fast.in_lds = false;
+        }
+        if (!fast.in_lds) {
+            fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
+            fast.stack_levels = levels_for(0, fast.wgs_per_cu);
+        }
         if (const int forced = env_int("RTP_STACK_LEVELS", 0)) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
         if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
-        fast.in_lds = true;
-        fast.lds_bytes = (uint32_t)(scene_bytes + pool_bytes + (uint64_t)fast.stack_levels * per_level);
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : 0) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
         if (const int w = env_int("RTP_WGS_PER_CU", 0)) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
     }
     bool use_queue = false;
@@ -468,7 +477,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             P.flag_list = sc->flag_list;
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
-            HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
+            if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
+            else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
             // … and are walked again in the reference's order, overwriting their slab entries
             rtk::KParams R = P;
             R.queue = sc->queue + kQueueRework + pass;

@@ -154,7 +154,7 @@ int main() {
         rtaccel::Packed pk;
         CHECK(rtaccel::pack_scene(hs.desc(), rtaccel::TreeMode::Guarded, pk).empty());
         CHECK(pk.guard.ok && pk.guard.reason.empty());
-        CHECK(pk.guard.num_small == 485 && pk.guard.large.size() == 4);        // the ground sphere is the one "large" sphere
+        CHECK(pk.guard.num_small == 485 && pk.guard.num_large == 1);           // the ground sphere is the one "large" sphere
         CHECK(pk.leaf_boxes.empty());                                          // leaf boxes are fl(c -/+ r): derived in the kernel
         CHECK(pk.guard.d0_sq > 4 * pk.guard.cluster_radius * pk.guard.cluster_radius * 0.99f);
         // every child box of the walk's tree holds the sphere below it with the documented margin
@@ -179,13 +179,22 @@ int main() {
                 ++leaves_seen;
             }
         CHECK(leaves_seen == hs.spheres.size());
-        // not eligible: planes; a sphere in two leaves; a leaf box that does not hold its sphere
+        // planes are eligible (their exact leaf boxes always travel as a table); a plane of unknown type is not
         rtp::HostScene with_plane;
         o.textured_floor_quad = true;
         o.texture_size = 8;
         rtp::build_rtiow_scene(o, with_plane);
         CHECK(rtaccel::pack_scene(with_plane.desc(), rtaccel::TreeMode::Guarded, pk).empty());
-        CHECK(!pk.guard.ok && pk.guard.reason == "scene has planes" && pk.num_tnodes > 0);
+        CHECK(pk.guard.ok && pk.plane_leaf_boxes.size() == with_plane.planes.size() * 8 && pk.num_tnodes > 0);
+        {
+            std::vector<rt_plane> planes(with_plane.planes);
+            rt_scene_desc dp = with_plane.desc();
+            planes[0].type = 7;
+            dp.planes = planes.data();
+            CHECK(rtaccel::pack_scene(dp, rtaccel::TreeMode::Guarded, pk).empty());
+            CHECK(!pk.guard.ok && pk.guard.reason == "plane of unknown type");
+        }
+        // not eligible: a sphere in two leaves; a leaf box that does not hold its sphere
         std::vector<rt_bvh_node> nodes(hs.nodes);
         rt_scene_desc d = hs.desc();
         d.nodes = nodes.data();

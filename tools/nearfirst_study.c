@@ -155,7 +155,7 @@ static unsigned long long depth_hist[40];
 static double g_max_ratio;       /* max observed (enter' - t) / bound over accepted hits */
 static float g_beta = 16 * 5.96e-8f;
 static unsigned long long n_far, n_far_flag;
-static float g_bs[6];
+static float g_bs[6], g_rs, g_fark;
 static int g_levels = 64;
 static float *g_rmax;            /* per SAH node: largest radius below */
 static void sah_ray(const ray *r, float c_ref, int prim_ref) {
@@ -163,7 +163,16 @@ static void sah_ray(const ray *r, float c_ref, int prim_ref) {
     struct { int idx; float enter; } stack[64]; int sp = 0, maxsp = 0;
     const float inv_len = 1.0f / sqrtf(lensq(r->d));
     const float bd = g_beta * inv_len;
-    { float dd = 0; for (int a = 0; a < 3; a++) dd += (r->o.e[a] - g_sc[a]) * (r->o.e[a] - g_sc[a]); if (dd > g_d0 * g_d0) { n_far++; float e; if (dd > 800.0f * 800.0f || aabb_hit_e(g_bs, r, 0.001f, 1e30f, &e)) { flag = 1; n_far_flag++; if (n_far_flag % 3000 == 1) fprintf(stderr, "far: o (%.2f %.2f %.3f) d (%.3f %.3f %.4f) e %.3f\n", r->o.e[0], r->o.e[1], r->o.e[2], r->d.e[0], r->d.e[1], r->d.e[2], e); } } }
+    {   /* far-origin test, as guard_origin() in the kernel */
+        float dd = 0; for (int a = 0; a < 3; a++) dd += (r->o.e[a] - g_sc[a]) * (r->o.e[a] - g_sc[a]);
+        if (dd > g_d0 * g_d0) {
+            n_far++;
+            const float reach = sqrtf(dd) + g_rs, grow = g_fark * reach * reach;
+            float gb[6], e;
+            for (int a = 0; a < 3; a++) { gb[2 * a] = g_bs[2 * a] - grow; gb[2 * a + 1] = g_bs[2 * a + 1] + grow; }
+            if (aabb_hit_e(gb, r, 0.001f, 1e30f, &e) || !(grow < 1e30f)) { flag = 1; n_far_flag++; }
+        }
+    }
     int cur = 0; float cur_enter = 0.001f; int have = 1;
     v_sah++;
     { float e0; if (!aabb_hit_e(g_s[0].box, r, 0.001f, 1e30f, &e0)) have = 0; cur_enter = e0; }
@@ -243,12 +252,20 @@ int main(int argc, char **argv) {
             if (sc.spheres[i].center.e[a] < lo[a]) lo[a] = sc.spheres[i].center.e[a];
             if (sc.spheres[i].center.e[a] > hi[a]) hi[a] = sc.spheres[i].center.e[a]; }
         for (int a = 0; a < 3; a++) g_sc[a] = 0.5f * (lo[a] + hi[a]);
-        { float rm = 0; for (int i = 0; i < sc.num_spheres; i++) if (sc.spheres[i].radius < 100 && sc.spheres[i].radius > rm) rm = sc.spheres[i].radius;
-          for (int a = 0; a < 3; a++) { g_bs[2 * a] = lo[a] - rm - 1.0f; g_bs[2 * a + 1] = hi[a] + rm + 1.0f; } }
+        float rmin = 1e30f; g_rs = 0;
+        for (int a = 0; a < 3; a++) { g_bs[2 * a] = 1e30f; g_bs[2 * a + 1] = -1e30f; }
+        for (int i = 0; i < sc.num_spheres; i++) if (sc.spheres[i].radius < 100) {
+            float dc = 0; for (int a = 0; a < 3; a++) dc += (sc.spheres[i].center.e[a] - g_sc[a]) * (sc.spheres[i].center.e[a] - g_sc[a]);
+            if (sqrtf(dc) + sc.spheres[i].radius > g_rs) g_rs = sqrtf(dc) + sc.spheres[i].radius;
+            if (sc.spheres[i].radius < rmin) rmin = sc.spheres[i].radius;
+            for (int a = 0; a < 3; a++) { if (g_rbox[6 * i + 2 * a] < g_bs[2 * a]) g_bs[2 * a] = g_rbox[6 * i + 2 * a]; if (g_rbox[6 * i + 2 * a + 1] > g_bs[2 * a + 1]) g_bs[2 * a + 1] = g_rbox[6 * i + 2 * a + 1]; }
+        }
+        g_fark = g_gamma / (2 * rmin);
+        { float reach = sqrtf(0.08f * rmin * rmin / g_gamma); if (reach < 2 * g_rs) reach = 2 * g_rs; g_d0 = reach - g_rs; }
         if (argc > 7) g_d0 = (float)atof(argv[7]);
         for (int i = 0; i < sc.num_spheres; i++) {
             float dc = 0; for (int a = 0; a < 3; a++) dc += (sc.spheres[i].center.e[a] - g_sc[a]) * (sc.spheres[i].center.e[a] - g_sc[a]);
-            const float reach = sqrtf(dc) + g_d0 + sc.spheres[i].radius;
+            const float reach = sc.spheres[i].radius < 100 ? g_d0 + g_rs : 1.25f * 2002.0f;
             const float eps = g_gamma * reach * reach / (2 * sc.spheres[i].radius);
             for (int a = 0; a < 3; a++) { g_pbox[6 * i + 2 * a] -= eps; g_pbox[6 * i + 2 * a + 1] += eps; }
             if (i < 3 || i == sc.num_spheres - 1) printf("sphere %d r %.3g eps %.3g\n", i, sc.spheres[i].radius, eps);
