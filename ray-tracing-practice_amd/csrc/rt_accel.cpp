@@ -352,7 +352,11 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                         rs = std::max(rs, dist(sc, d.spheres[i].center.e) + d.spheres[i].radius);
                 // origins within d0 of the centre: margin 4 % of the smallest radius, but never less than the
                 // cluster itself (paths start on its surfaces)
+                // … and up to 25 % of it where that buys origins out to 5 cluster radii from the centre (a camera
+                // orbiting a compact scene of tiny spheres must not make every primary ray a far-origin ray)
                 double reach = std::sqrt(0.08 * r_min_small * r_min_small / double(kGuardGamma));
+                const double reach_25 = std::sqrt(0.50 * r_min_small * r_min_small / double(kGuardGamma));
+                reach = std::max(reach, std::min(6.0 * rs, reach_25));
                 if (reach < 2.0 * rs) reach = 2.0 * rs;
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)

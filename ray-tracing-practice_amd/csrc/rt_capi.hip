@@ -53,6 +53,14 @@ bool threaded_forced() {
     const char *v = getenv("RTP_TRAVERSAL");
     return v && std::string(v) == "threaded";
 }
+// Small trees gain nothing from the near-first walk (the reference's own scenes, ~200 primitives,
+// are shading-bound: 5.15 vs 5.22 Gsamples/s), so they keep the simpler exact walk unless
+// RTP_TRAVERSAL=guarded asks for the guarded one.
+bool guarded_wanted(int64_t primitives) {
+    const char *v = getenv("RTP_TRAVERSAL");
+    if (v && std::string(v) == "guarded") return true;
+    return primitives >= env_int("RTP_GUARD_MIN_PRIMS", 256);
+}
 
 }  // namespace
 
@@ -303,7 +311,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     }
 
     // ---- guarded near-first walk: only for eligible scenes that fit LDS with a useful stack
-    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0;
+    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0 && guarded_wanted((int64_t)P.num_spheres + P.num_planes);
     Shape fast{};
     if (guarded) {
         // the margins were sized for ray origins within origin_radius of origin_center: so must the camera be

@@ -404,12 +404,47 @@ def test_guarded_walk_far_camera_and_ties():
     dev = rb.DeviceScene(host, device=0)
     cam = rb.make_camera(200, 120, 40.0, (6, 5, 2.5), (0.7, 0.8, 0), (0.6, 0.7, 0.9), 6, 20)
     fb, t = dev.render_to_host(cam)
+    assert t.guarded == 0                                    # small trees keep the exact walk unless asked
+    try:
+        os.environ["RTP_TRAVERSAL"] = "guarded"
+        fb, t = dev.render_to_host(cam)
+    finally:
+        os.environ.pop("RTP_TRAVERSAL", None)
     assert t.guarded == 1 and t.flagged_samples > 0          # the ties
     assert_same_frame(fb, ob.render(host, cam, threads=8), "coincident spheres")
 
 
-def test_guarded_walk_random_sphere_scenes():
-    """Sphere-only random scenes (the ones eligible for the guarded walk): radii over three decades,
+@pytest.fixture
+def force_guarded():
+    os.environ["RTP_TRAVERSAL"] = "guarded"
+    yield
+    os.environ.pop("RTP_TRAVERSAL", None)
+
+
+def test_guarded_walk_on_plane_scenes(config_scene, force_guarded):
+    """Scenes with quads, ellipses and triangles through the guarded walk (asked for explicitly:
+    these trees are small): the config scene at C1, and random mixed scenes with axis-aligned
+    (thin-box) and tilted planes."""
+    host, dev = config_scene
+    base = host.frame_camera(0)
+    cam = rb.make_camera(400, 225, 50.0, list(base.origin.e), (0.0, 0.0, 4.5), (0, 0, 0), 16, 10)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1, dev.guard_reason()
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "config scene, guarded")
+    rng = np.random.default_rng(4242)
+    for trial in range(8):
+        host = _random_scene(rng, int(rng.integers(1, 80)), int(rng.integers(1, 40)), axis_aligned=trial % 2 == 0)
+        dev = rb.DeviceScene(host, device=0)
+        eye = rng.uniform(-9, 9, 3)
+        cam = rb.make_camera(int(rng.integers(33, 160)), int(rng.integers(17, 90)), float(rng.uniform(20, 100)), eye, rng.uniform(-2, 2, 3),
+                             rng.uniform(0, 1, 3), int(rng.integers(1, 7)), int(rng.integers(1, 30)))
+        fb, t = dev.render_to_host(cam)
+        assert dev.guard_reason() == "" and t.guarded == 1
+        assert_same_frame(fb, ob.render(host, cam, threads=8), f"mixed scene {trial}, guarded")
+
+
+def test_guarded_walk_random_sphere_scenes(force_guarded):
+    """Sphere-only random scenes through the guarded walk: radii over 2.5 decades,
     overlaps, a huge ground sphere in half of them, cameras inside and far outside the cluster."""
     rng = np.random.default_rng(77)
     for trial in range(12):
