@@ -42,12 +42,93 @@ struct SahBuilder {
 
     explicit SahBuilder(std::vector<LeafRef> &l) : leaves(l) {}
 
+    static constexpr int kBinnedAbove = 512, kBins = 32;
+
+    // Partitions [first, last) by the cheapest of 3 x 31 bin boundaries; returns the split position.
+    int binned_split(int first, int last) {
+        const int n = last - first;
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = first; k < last; ++k)
+            for (int a = 0; a < 3; ++a) {
+                const float c = leaves[static_cast<size_t>(k)].box[2 * a] + leaves[static_cast<size_t>(k)].box[2 * a + 1];   // 2 x centroid
+                clo[a] = fminf(clo[a], c);
+                chi[a] = fmaxf(chi[a], c);
+            }
+        int best_axis = -1, best_bin = -1;
+        float best_cost = INFINITY;
+        for (int a = 0; a < 3; ++a) {
+            if (!(chi[a] > clo[a])) continue;
+            const float scale = kBins / (chi[a] - clo[a]);
+            float bbox[kBins][6];
+            int count[kBins];
+            for (int b = 0; b < kBins; ++b) {
+                count[b] = 0;
+                for (int k = 0; k < 3; ++k) { bbox[b][2 * k] = INFINITY; bbox[b][2 * k + 1] = -INFINITY; }
+            }
+            for (int k = first; k < last; ++k) {
+                const LeafRef &l = leaves[static_cast<size_t>(k)];
+                int b = static_cast<int>((l.box[2 * a] + l.box[2 * a + 1] - clo[a]) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                count[b]++;
+                box_union(bbox[b], l.box, bbox[b]);
+            }
+            float right_area_bin[kBins];
+            int right_count[kBins];
+            float acc[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+            int cnt = 0;
+            for (int b = kBins - 1; b >= 1; --b) {
+                if (count[b]) box_union(acc, bbox[b], acc);
+                cnt += count[b];
+                right_area_bin[b] = cnt ? half_area(acc) : 0.0f;
+                right_count[b] = cnt;
+            }
+            float lacc[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+            int lcnt = 0;
+            for (int b = 1; b < kBins; ++b) {       // boundary between bin b-1 and b
+                if (count[b - 1]) box_union(lacc, bbox[b - 1], lacc);
+                lcnt += count[b - 1];
+                if (lcnt == 0 || right_count[b] == 0) continue;
+                const float cost = half_area(lacc) * lcnt + right_area_bin[b] * right_count[b];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        if (best_axis < 0) {      // all centroids coincide: any split will do
+            return first + n / 2;
+        }
+        const int a = best_axis;
+        const float scale = kBins / (chi[a] - clo[a]);
+        const float lo = clo[a];
+        const int bb = best_bin;
+        auto mid = std::partition(leaves.begin() + first, leaves.begin() + last, [a, scale, lo, bb](const LeafRef &l) {
+            int b = static_cast<int>((l.box[2 * a] + l.box[2 * a + 1] - lo) * scale);
+            b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+            return b < bb;
+        });
+        const int pos = static_cast<int>(mid - leaves.begin());
+        return (pos == first || pos == last) ? first + n / 2 : pos;
+    }
+
     int32_t build(int first, int last, float out_box[6]) {
         if (last - first == 1) {
             std::memcpy(out_box, leaves[first].box, sizeof(float) * 6);
             return leaves[first].code;
         }
         const int n = last - first;
+        if (n > kBinnedAbove) {
+            // big ranges: binned SAH (32 bins per axis over the centroid bounds, O(n) per level) — the full
+            // sweep below sorts the range three times per node, 0.6 s for 100 k primitives
+            const int mid = binned_split(first, last);
+            const int32_t me = static_cast<int32_t>(nodes.size());
+            nodes.push_back(BuildNode{});
+            float lb[6], rb[6];
+            const int32_t l = build(first, mid, lb);
+            const int32_t r = build(mid, last, rb);
+            nodes[static_cast<size_t>(me)].child[0] = l;
+            nodes[static_cast<size_t>(me)].child[1] = r;
+            box_union(lb, rb, out_box);
+            std::memcpy(nodes[static_cast<size_t>(me)].box, out_box, sizeof(float) * 6);
+            return me;
+        }
         int best_axis = -1, best_split = -1;
         float best_cost = INFINITY;
         for (int axis = 0; axis < 3; ++axis) {
