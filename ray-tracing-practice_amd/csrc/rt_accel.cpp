@@ -496,6 +496,34 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
         float rb[6];
         out.root = b.build(0, static_cast<int>(leaves.size()), rb);
         bnodes = std::move(b.nodes);
+        if (mode == TreeMode::Guarded && out.root >= 0) {
+            // top levels first (breadth-first from the root): a scene too big for LDS keeps records
+            // [0, num_top_pairs) there as a "treelet" and reads the deeper ones through L1/L2
+            const int32_t count = static_cast<int32_t>(bnodes.size());
+            const int32_t want_top = std::min<int32_t>(count, 2048);
+            std::vector<int32_t> new_of(static_cast<size_t>(count), -1), bfs;
+            bfs.reserve(static_cast<size_t>(want_top));
+            bfs.push_back(out.root);
+            for (size_t head = 0; head < bfs.size(); ++head)
+                for (int c = 0; c < 2; ++c) {
+                    const int32_t ch = bnodes[static_cast<size_t>(bfs[head])].child[c];
+                    if (ch >= 0 && static_cast<int32_t>(bfs.size()) < want_top) bfs.push_back(ch);
+                }
+            int32_t next_index = 0;
+            for (int32_t k : bfs) new_of[static_cast<size_t>(k)] = next_index++;
+            out.num_top_pairs = next_index;
+            for (int32_t k = 0; k < count; ++k)
+                if (new_of[static_cast<size_t>(k)] < 0) new_of[static_cast<size_t>(k)] = next_index++;
+            std::vector<BuildNode> moved(static_cast<size_t>(count));
+            for (int32_t k = 0; k < count; ++k) {
+                BuildNode n = bnodes[static_cast<size_t>(k)];
+                for (int c = 0; c < 2; ++c)
+                    if (n.child[c] >= 0) n.child[c] = new_of[static_cast<size_t>(n.child[c])];
+                moved[static_cast<size_t>(new_of[static_cast<size_t>(k)])] = n;
+            }
+            bnodes = std::move(moved);
+            out.root = new_of[static_cast<size_t>(out.root)];
+        }
     } else {
         // same topology as the caller's tree: internal node k → dense index, in array order
         std::vector<int32_t> dense(static_cast<size_t>(d.num_nodes), -1);

@@ -45,6 +45,7 @@ struct Packed {
     int32_t num_top = 0, xroot = 0;
     int32_t root = kTraversalDone; // node code of the root (leaf code when the scene has one primitive)
     int32_t num_internal = 0;
+    int32_t num_top_pairs = 0;     // Guarded: nodes [0, num_top_pairs) are the top of the tree, breadth-first
     int32_t max_depth = 0;         // longest root→leaf path in internal nodes = traversal stack bound
     // Guarded near-first walk (TreeMode::Guarded): `nodes` then is an SAH tree over
     // leaf boxes INFLATED by a per-sphere margin, and the kernel sends every sample whose result

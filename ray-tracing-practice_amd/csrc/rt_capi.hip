@@ -67,7 +67,7 @@ bool guarded_wanted(int64_t primitives) {
 struct rt_scene {
     int device = 0;
     float4 *tnodes = nullptr, *xnodes = nullptr;
-    int32_t num_tnodes = 0, num_top = 0;
+    int32_t num_tnodes = 0, num_top = 0, num_top_pairs = 0;
     float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
@@ -226,6 +226,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (hipEventCreate(&sc->ev_start) != hipSuccess || hipEventCreate(&sc->ev_stop) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
     sc->num_internal = pk.num_internal;
+    sc->num_top_pairs = pk.num_top_pairs;
     sc->num_spheres = (int32_t)pk.sphere_mat.size();
     sc->num_planes = (int32_t)(pk.planes.size() / 20);
     sc->num_materials = (int32_t)(pk.materials.size() / 12);
@@ -340,12 +341,21 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             if (fast.stack_levels < min_levels) fast.in_lds = false;
         }
         if (!fast.in_lds) {
+            // tables through L1/L2: a 12-entry stack per lane (deeper ones are rare enough to flag), the rest of
+            // the workgroup's LDS share holds the top of the tree
             fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
             fast.stack_levels = levels_for(0, fast.wgs_per_cu);
+            if (fast.stack_levels > 12) fast.stack_levels = 12;
         }
         if (const int forced = env_int("RTP_STACK_LEVELS", 0)) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
         if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : 0) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
+        if (!fast.in_lds && !env_int("RTP_NO_TREELET", 0)) {
+            const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
+            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level;
+            const int64_t fit = budget > used ? (int64_t)((budget - used) / 64) : 0;
+            fast.num_top = (int32_t)(fit < sc->num_top_pairs ? fit : sc->num_top_pairs);
+        }
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * 64) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
         if (const int w = env_int("RTP_WGS_PER_CU", 0)) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
     }
     bool use_queue = false;
@@ -482,6 +492,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         } else if (guarded) {
             // near-first walk; samples it cannot vouch for go to the list …
             P.stack_levels = fast.stack_levels;
+            P.num_top = fast.num_top;
             P.flag_list = sc->flag_list;
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
