@@ -123,7 +123,7 @@ def main():
     fb = torch.zeros((local_rows, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
 
-    kernel_ms, trace_ms, launches, guarded, flagged = [], [], [], [], []
+    kernel_ms, trace_ms, launches, guarded, flagged, rework_ms = [], [], [], [], [], []
 
     def step(record):
         dev.render(cam, fb.data_ptr(), shard=shard, stream=stream, sync=False)
@@ -139,6 +139,7 @@ def main():
             launches.append(t.trace_launches)
             guarded.append(t.guarded)
             flagged.append(t.flagged_samples)
+            rework_ms.append(t.rework_ms)
         return frame
 
     def fence():
@@ -216,9 +217,9 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "rtk::render_kernel<true,false> (+ exact re-walk render_kernel<true,true>)" if guarded and guarded[0]
-                      else "rtk::render_kernel<true,true>",
+            "kernel": "rtk::render_kernel<true,false>" if guarded and guarded[0] else "rtk::render_kernel<true,true>",
             "launches_per_step": n_launch, "launch_ms": round(launch_ms, 3),
+            "rework_launch_ms": round(float(np.mean(rework_ms)) / max(n_launch, 1), 3) if rework_ms else None,
             "flagged_sample_fraction": round(float(np.mean(flagged)) / max(local_samples, 1), 6) if flagged else None,
             "step_kernels_ms": round(k_ms, 3),
             "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),

@@ -140,10 +140,10 @@ typedef struct rt_timing {
     uint32_t lds_bytes;
     uint32_t scene_in_lds;    /* 1 when the whole traversal structure is LDS-resident */
     uint32_t trace_launches;  /* passes: launches of the path-tracing kernel (one per pass of samples per pixel) */
-    float    trace_ms;        /* sum of the passes' hipEvent durations (the dominant kernel; a guarded pass includes
-                                 its exact re-walk launch) */
+    float    trace_ms;        /* sum of the trace launches' hipEvent durations (the dominant kernel) */
     uint32_t guarded;         /* 1: guarded near-first walk + exact re-walk of flagged samples; 0: exact walk only */
     uint64_t flagged_samples; /* samples the guarded walk handed to the exact walk (0 when not guarded) */
+    float    rework_ms;       /* sum of the exact re-walk launches' durations (0 when not guarded) */
 } rt_timing;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */

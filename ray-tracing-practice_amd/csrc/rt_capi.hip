@@ -80,7 +80,7 @@ struct rt_scene {
     size_t flag_cap = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    std::vector<hipEvent_t> pass_events;   // pairs around each trace launch (first kTimedPasses passes)
+    std::vector<hipEvent_t> pass_events;   // per pass: before the trace launch, after it, after the exact re-walk (first kTimedPasses passes)
     int timed_passes = 0;
     rt_timing last{};
     int last_passes = 0;
@@ -436,7 +436,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (exact.in_lds) return launch(rtk::render_kernel<true, true>, KP, grid, exact.lds_bytes);
         return launch(rtk::render_kernel<false, true>, KP, grid, exact.lds_bytes);
     };
-    while ((int)sc->pass_events.size() < 2 * (passes < kTimedPasses ? passes : kTimedPasses)) {
+    while ((int)sc->pass_events.size() < 3 * (passes < kTimedPasses ? passes : kTimedPasses)) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         sc->pass_events.push_back(e);
@@ -476,7 +476,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     for (int pass = 0; pass < passes; ++pass) {
         // samples [pass_first, pass_first + pass_count) of every pixel, traced in any order into the slab …
         const bool timed_pass = pass < kTimedPasses;
-        if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[2 * pass], stream));
+        if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass], stream));
         P.pass_first = pass * pass_size;
         P.pass_count = P.spp - P.pass_first < pass_size ? P.spp - P.pass_first : pass_size;
         P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
@@ -498,6 +498,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
             if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
             else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
+            if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
             // … and are walked again in the reference's order, overwriting their slab entries
             rtk::KParams R = P;
             R.queue = sc->queue + kQueueRework + pass;
@@ -508,7 +509,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         } else {
             HIP_TRY(launch_exact(P, wgs));
         }
-        if (timed_pass) { HIP_TRY(hipEventRecord(sc->pass_events[2 * pass + 1], stream)); sc->timed_passes = pass + 1; }
+        if (timed_pass) {
+            if (!guarded) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
+            HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 2], stream));
+            sc->timed_passes = pass + 1;
+        }
         // … then added to the pixel sums strictly in sample order
         hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 255) / 256), dim3(256), 0, stream, d_fb_sum,
                            (const float4 *)sc->slab, num_pixels, P.pass_count, pass == 0 ? 1 : 0);
@@ -534,15 +539,21 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
     if (sc->timed) {
         HIP_TRY(hipEventSynchronize(sc->ev_stop));
         HIP_TRY(hipEventElapsedTime(&sc->last.kernel_ms, sc->ev_start, sc->ev_stop));
-        float sum = 0.0f;
+        float sum = 0.0f, rework = 0.0f;
         for (int p = 0; p < sc->timed_passes; ++p) {
             float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[2 * p], sc->pass_events[2 * p + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[3 * p], sc->pass_events[3 * p + 1]));
             sum += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[3 * p + 1], sc->pass_events[3 * p + 2]));
+            rework += ms;
         }
         // passes beyond the individually timed ones are priced at the mean of the timed ones
-        if (sc->timed_passes > 0) sum *= (float)sc->last.trace_launches / (float)sc->timed_passes;
+        if (sc->timed_passes > 0) {
+            sum *= (float)sc->last.trace_launches / (float)sc->timed_passes;
+            rework *= (float)sc->last.trace_launches / (float)sc->timed_passes;
+        }
         sc->last.trace_ms = sum;
+        sc->last.rework_ms = rework;
         if (sc->last.guarded) {
             std::vector<uint32_t> counts((size_t)sc->last_passes);
             HIP_TRY(hipMemcpy(counts.data(), sc->queue + kQueueFlag, counts.size() * 4, hipMemcpyDeviceToHost));

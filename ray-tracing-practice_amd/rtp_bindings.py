@@ -61,7 +61,7 @@ class Shard(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("num_workgroups", C.c_uint32), ("workgroup_size", C.c_uint32),
                 ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("trace_launches", C.c_uint32),
-                ("trace_ms", C.c_float), ("guarded", C.c_uint32), ("flagged_samples", C.c_uint64)]
+                ("trace_ms", C.c_float), ("guarded", C.c_uint32), ("flagged_samples", C.c_uint64), ("rework_ms", C.c_float)]
 
 
 class ConfigInfo(C.Structure):
