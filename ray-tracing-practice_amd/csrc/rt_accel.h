@@ -8,9 +8,9 @@
 //   spheres    1 x float4: center.xyz, radius;  sphere_mat: int per sphere
 //   planes     5 x float4: (normal, D) (w, type) (u, material) (v, 0) (base, 0)
 //   materials  3 x float4: (albedo, type | texture_id << 2) (emit, fuzz) (absorption, ir)
-// Leaf boxes are copied bit for bit from the caller's BVH leaves — they are the gate the
-// reference applies before each primitive test (include/bvh.h:36-37), so the set of primitives a
-// ray can hit is the same; inner boxes are exact fmin/fmax unions of leaf boxes.
+// TreeMode::Reference / Sah: leaf boxes are copied bit for bit from the caller's BVH leaves; inner
+// boxes are exact fmin/fmax unions of leaf boxes.  TreeMode::Guarded (what rt_scene_create uses):
+// the same SAH build over leaf boxes inflated by a per-primitive margin, see Packed::Guard.
 #pragma once
 #include <cstdint>
 #include <string>
