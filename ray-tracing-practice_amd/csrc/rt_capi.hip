@@ -496,6 +496,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             P.flag_list = sc->flag_list;
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
+            if (const int tiny = env_int("RTP_FLAG_CAP", 0)) P.flag_cap = (uint32_t)tiny < P.flag_cap ? (uint32_t)tiny : P.flag_cap;   // test hook: overflow path
             if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
             else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
             if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));

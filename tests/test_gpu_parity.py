@@ -379,8 +379,40 @@ def test_guarded_walk_flags_and_rewalks(rtiow):
         fb2, t2 = dev.render_to_host(cam)
         assert t2.guarded == 1 and t2.flagged_samples > 4 * t.flagged_samples
         assert_same_frame(fb2, fb, "2-entry stack")
+        # a flagged-sample list that overflows its capacity makes the exact walk redo every sample
+        os.environ["RTP_FLAG_CAP"] = "1000"
+        fb3, t3 = dev.render_to_host(cam)
+        assert t3.guarded == 1 and t3.flagged_samples > 1000
+        assert_same_frame(fb3, fb, "overflowed flag list")
     finally:
         os.environ.pop("RTP_STACK_LEVELS", None)
+        os.environ.pop("RTP_FLAG_CAP", None)
+
+
+def test_guarded_scene_handles_are_independent_and_reusable():
+    """Two scene handles alive at once, renders of growing and shrinking sizes on each (slab and flag
+    list regrow), an asynchronous render whose timing is read later: all frames are the oracle's."""
+    import torch
+    a = rb.HostScene.rtiow()
+    b = rb.HostScene.rtiow(seed=777, half_extent=9)
+    da, dbv = rb.DeviceScene(a, device=0), rb.DeviceScene(b, device=0)
+    for (w, h, spp) in ((64, 40, 2), (300, 170, 3), (48, 30, 70)):
+        for host, dev in ((a, da), (b, dbv)):
+            cam = rb.rtiow_camera(w, h, spp, 50)
+            fb, t = dev.render_to_host(cam)
+            assert t.guarded == 1
+            assert_same_frame(fb, ob.render(host, cam, threads=8), f"{w}x{h}x{spp}")
+    cam = rb.rtiow_camera(200, 100, 5, 50)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    f1 = torch.zeros((100, 200, 3), dtype=torch.float32, device="cuda:0")
+    f2 = torch.zeros((100, 200, 3), dtype=torch.float32, device="cuda:0")
+    da.render(cam, f1.data_ptr(), stream=s1.cuda_stream, sync=False)         # two scenes, two streams, in flight together
+    dbv.render(cam, f2.data_ptr(), stream=s2.cuda_stream, sync=False)
+    s1.synchronize(); s2.synchronize()
+    ta, tb = da.last_timing(), dbv.last_timing()
+    assert ta.guarded == 1 and tb.guarded == 1 and ta.trace_ms > 0 and tb.rework_ms > 0
+    assert_same_frame(f1.cpu().numpy(), ob.render(a, cam, threads=8), "async scene a")
+    assert_same_frame(f2.cpu().numpy(), ob.render(b, cam, threads=8), "async scene b")
 
 
 def test_guarded_walk_far_camera_and_ties():
