@@ -327,7 +327,7 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
     }
 
     // ---- guarded mode: eligibility, per-primitive inflation, exact leaf boxes for the final check
-    if (mode == TreeMode::Guarded) {
+    if (mode == TreeMode::Guarded || mode == TreeMode::GuardedLeaves) {
         Packed::Guard &g = out.guard;
         std::string why;
         const double u = 5.9604645e-8;       // 2^-24
@@ -489,7 +489,18 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
 
     // ---- traversal tree
     std::vector<BuildNode> bnodes;
-    if (leaves.empty()) {
+    if (mode == TreeMode::GuardedLeaves) {
+        // the caller builds the tree itself (device builder, rt_build.hip) from the inflated leaves
+        out.root = kTraversalDone;
+        if (out.guard.ok) {
+            out.guard_leaf_boxes.reserve(leaves.size() * 6);
+            out.guard_leaf_codes.reserve(leaves.size());
+            for (const LeafRef &l : leaves) {
+                out.guard_leaf_boxes.insert(out.guard_leaf_boxes.end(), l.box, l.box + 6);
+                out.guard_leaf_codes.push_back(l.code);
+            }
+        }
+    } else if (leaves.empty()) {
         out.root = kTraversalDone;
     } else if (mode == TreeMode::Sah || mode == TreeMode::Guarded || d.nodes[0].left < 0) {
         SahBuilder b(leaves);

@@ -68,9 +68,13 @@ struct Packed {
     std::vector<float> leaf_boxes;        // 8 floats per sphere: the caller's exact leaf box (+2 pad), for the final check
                                           // (empty when every box is exactly fl(c -/+ r): the kernel recomputes it)
     std::vector<float> plane_leaf_boxes;  // 8 floats per plane, same purpose
+    std::vector<float> guard_leaf_boxes;  // GuardedLeaves: 6 floats per leaf, inflated
+    std::vector<int32_t> guard_leaf_codes;
 };
 
-enum class TreeMode { Reference, Sah, Guarded };
+// GuardedLeaves: everything of Guarded except the tree itself — the inflated leaves are returned in
+// guard_leaf_boxes / guard_leaf_codes for a device-side builder (rt_build.h).
+enum class TreeMode { Reference, Sah, Guarded, GuardedLeaves };
 
 // Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2.
 constexpr float kGuardGamma = 8.0f * 5.9604645e-8f;

@@ -10,6 +10,7 @@
 
 #include "../../include/rtp_amd.h"
 #include "rt_accel.h"
+#include "rt_build.h"
 #include "rt_device_math.h"
 #include "rt_kernel.hip.inc"
 #include "rt_kernel_queue.hip.inc"
@@ -86,6 +87,7 @@ struct rt_scene {
     int last_passes = 0;
     bool timed = false;
     int num_cus = 0;
+    float build_ms = 0.0f;          // device BVH build time (RTP_BUILD=device), else 0
 };
 
 namespace {
@@ -195,8 +197,16 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARG, "null argument");
     *out_scene = nullptr;
     rtaccel::Packed pk;
-    const std::string err = rtaccel::pack_scene(*desc, rtaccel::TreeMode::Guarded, pk);
+    // RTP_BUILD=device: the guarded walk's tree is built on the GPU (LBVH, rt_build.hip) instead of the host's SAH
+    // builder — any tree over the inflated leaves gives the same image
+    const char *build_env = getenv("RTP_BUILD");
+    const bool device_build = build_env && std::string(build_env) == "device";
+    std::string err = rtaccel::pack_scene(*desc, device_build ? rtaccel::TreeMode::GuardedLeaves : rtaccel::TreeMode::Guarded, pk);
     if (!err.empty()) return fail(RT_ERR_INVALID_ARG, err);
+    if (device_build && !pk.guard.ok) {       // not eligible for the guarded walk: nothing to build, exact walk only
+        err = rtaccel::pack_scene(*desc, rtaccel::TreeMode::Guarded, pk);
+        if (!err.empty()) return fail(RT_ERR_INVALID_ARG, err);
+    }
 
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
@@ -208,7 +218,17 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, sc->device) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
     sc->num_cus = prop.multiProcessorCount;
-    if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
+    if (device_build && pk.guard.ok) {
+        rtbuild::DeviceTree tree;
+        const std::string berr = rtbuild::build_lbvh(pk.guard_leaf_boxes.data(), pk.guard_leaf_codes.data(), (int32_t)pk.guard_leaf_codes.size(), tree);
+        if (!berr.empty()) return bail(fail(RT_ERR_HIP, "device BVH build: " + berr));
+        sc->nodes = (float4 *)tree.nodes;
+        pk.num_internal = tree.num_internal;
+        pk.root = tree.root;
+        pk.max_depth = tree.depth;
+        pk.num_top_pairs = 0;
+        sc->build_ms = tree.build_ms;
+    } else if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
     if ((st = upload(pk.tnodes, (void **)&sc->tnodes)) != RT_OK) return bail(st);
     sc->num_tnodes = pk.num_tnodes;
     if ((st = upload(pk.xnodes, (void **)&sc->xnodes)) != RT_OK) return bail(st);

@@ -475,6 +475,42 @@ def test_guarded_walk_on_plane_scenes(config_scene, force_guarded):
         assert_same_frame(fb, ob.render(host, cam, threads=8), f"mixed scene {trial}, guarded")
 
 
+def test_device_built_tree_gives_the_same_frames(force_guarded):
+    """RTP_BUILD=device: the guarded walk's tree is an LBVH built on the GPU (rt_build.hip).  Any tree
+    over the inflated leaf boxes must give the oracle's frame: S-rtiow (one huge + 485 small
+    spheres), mixed sphere/plane scenes, scenes of one and two primitives, equal Morton keys
+    (coincident spheres)."""
+    os.environ["RTP_BUILD"] = "device"
+    try:
+        host = rb.HostScene.rtiow()
+        dev = rb.DeviceScene(host, device=0)
+        cam = rb.rtiow_camera(320, 180, 8, 50)
+        fb, t = dev.render_to_host(cam)
+        assert t.guarded == 1
+        assert_same_frame(fb, ob.render(host, cam, threads=8), "S-rtiow on a device-built tree")
+        rng = np.random.default_rng(31337)
+        mats = [_material(0, albedo=(0.7, 0.6, 0.5)), _material(1, albedo=(0.8, 0.8, 0.9), fuzz=0.2), _material(2, ir=1.4)]
+        cases = [np.array([[0, 0, 0, 1, 0]], np.float32),                                   # one primitive: no tree at all
+                 np.array([[0, 0, 0, 1, 0], [1.5, 0.2, 0.1, 0.7, 1]], np.float32),           # two
+                 np.array([[0, 0, 0, 1, 0]] * 5 + [[2, 0, 0, 0.5, 2]] * 3, np.float32)]      # identical centres: equal keys
+        for k, spheres in enumerate(cases):
+            host = rb.HostScene.from_arrays(spheres, np.zeros((0, 11), np.float32), mats)
+            dev = rb.DeviceScene(host, device=0)
+            cam = rb.make_camera(120, 80, 45.0, (5, 4, 2), (0.5, 0, 0), (0.5, 0.6, 0.8), 4, 12)
+            fb, t = dev.render_to_host(cam)
+            assert_same_frame(fb, ob.render(host, cam, threads=8), f"tiny scene {k} on a device-built tree")
+        for trial in range(5):
+            host = _random_scene(rng, int(rng.integers(2, 120)), int(rng.integers(0, 40)), axis_aligned=trial % 2 == 0)
+            dev = rb.DeviceScene(host, device=0)
+            cam = rb.make_camera(int(rng.integers(33, 160)), int(rng.integers(17, 90)), float(rng.uniform(20, 100)), rng.uniform(-9, 9, 3),
+                                 rng.uniform(-2, 2, 3), rng.uniform(0, 1, 3), int(rng.integers(1, 7)), int(rng.integers(1, 30)))
+            fb, t = dev.render_to_host(cam)
+            assert t.guarded == 1
+            assert_same_frame(fb, ob.render(host, cam, threads=8), f"mixed scene {trial} on a device-built tree")
+    finally:
+        os.environ.pop("RTP_BUILD", None)
+
+
 def test_guarded_walk_random_sphere_scenes(force_guarded):
     """Sphere-only random scenes through the guarded walk: radii over 2.5 decades,
     overlaps, a huge ground sphere in half of them, cameras inside and far outside the cluster."""

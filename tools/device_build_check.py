@@ -1,0 +1,27 @@
+"""Developer tool (GPU): the guarded walk on a device-built LBVH (RTP_BUILD=device) against the host SAH tree."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ray-tracing-practice_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import rtp_bindings as rb
+import oracle_bindings as ob
+
+for half, (w, h, spp) in ((11, (960, 540, 32)), (158, (960, 540, 16))):
+    host = rb.HostScene.rtiow(half_extent=half, textured_quad=half > 11, texture_size=256)
+    cam = rb.rtiow_camera(w, h, spp, 50)
+    frames = {}
+    for build in ("host", "device"):
+        os.environ["RTP_BUILD"] = build
+        os.environ["RTP_TRAVERSAL"] = "guarded"
+        t0 = time.time()
+        dev = rb.DeviceScene(host, 0)
+        t_create = time.time() - t0
+        fb, t = dev.render_to_host(cam)
+        fb, t = dev.render_to_host(cam)
+        frames[build] = fb
+        n = w * h * spp
+        print(f"half {half} build {build:6s}: scene create {t_create * 1e3:7.1f} ms, frame {t.kernel_ms:8.2f} ms = {n / t.kernel_ms / 1e3:7.1f} Ms/s, "
+              f"guarded {t.guarded} flagged {100.0 * t.flagged_samples / n:.3f} % lds {t.lds_bytes}", flush=True)
+    print("   device-tree frame == host-tree frame:", bool(np.array_equal(frames["host"].view(np.uint32), frames["device"].view(np.uint32))))
+    rows = ob.render(host, cam, row0=200, row1=204, threads=16)
+    print("   device-tree frame rows == oracle:", bool(np.array_equal(rows.view(np.uint32), frames["device"][200:204].view(np.uint32))), flush=True)
