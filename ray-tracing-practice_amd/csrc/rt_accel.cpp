@@ -171,6 +171,37 @@ struct SahBuilder {
 
 }  // namespace
 
+// ---- binary16 with directed rounding (the walk's boxes may only grow) ------------------------------
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    if (exp == 0x1f) return bits_as_float((int32_t)(sign | 0x7f800000u | (man << 13)));
+    if (exp == 0) {
+        const float v = std::ldexp((float)man, -24);
+        return sign ? -v : v;
+    }
+    return bits_as_float((int32_t)(sign | ((exp + 112u) << 23) | (man << 13)));
+}
+// largest half <= f (toward_minus_inf) or smallest half >= f; finite results where a finite one exists
+uint16_t float_to_half_dir(float f, bool toward_minus_inf) {
+    if (std::isnan(f)) return toward_minus_inf ? 0xfc00u : 0x7c00u;      // -inf / +inf: the conservative end
+    if (f > 65504.0f) return toward_minus_inf ? 0x7bffu : 0x7c00u;
+    if (f < -65504.0f) return toward_minus_inf ? 0xfc00u : 0xfbffu;
+    // positive halves are ordered like their bit patterns: binary search on the magnitude
+    const float a = std::fabs(f);
+    uint32_t lo = 0, hi = 0x7bff;                    // largest magnitude pattern with value <= a
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (half_to_float((uint16_t)mid) <= a) lo = mid; else hi = mid - 1;
+    }
+    const bool exact = half_to_float((uint16_t)lo) == a;
+    const bool negative = std::signbit(f);
+    // rounding a positive value down / a negative value up keeps the smaller magnitude; otherwise the next one
+    const bool shrink = negative != toward_minus_inf;
+    uint32_t mag = lo;
+    if (!exact && !shrink) mag = lo + 1;              // <= 0x7c00 (inf) by the range checks above: 0x7bff + 1
+    return (uint16_t)((negative ? 0x8000u : 0u) | mag);
+}
+
 std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
     out = Packed{};
     if (d.num_spheres < 0 || d.num_planes < 0 || d.num_materials < 0 || d.num_nodes < 0 || d.num_textures < 0)
@@ -584,6 +615,25 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
         o[12] = bits_as_float(bnodes[k].child[0]);
         o[13] = bits_as_float(bnodes[k].child[1]);
         o[14] = 0; o[15] = 0;
+    }
+    // the guarded walk reads the pair boxes as binary16, rounded OUTWARD (its boxes only have to contain the
+    // inflated leaf boxes): 32 B per node instead of 64 — half the LDS footprint and half the read traffic.
+    //   8 halves: lo0.x hi0.x lo0.y hi0.y lo0.z hi0.z lo1.x hi1.x | 4 halves: lo1.y hi1.y lo1.z hi1.z, code0, code1
+    if (mode == TreeMode::Guarded) {
+        out.hnodes.assign(bnodes.size() * 8, 0.0f);
+        for (size_t k = 0; k < bnodes.size(); ++k) {
+            const float *o = &out.nodes[k * 16];        // lo0.xyz hi0.xyz lo1.xyz hi1.xyz
+            uint16_t h[12];
+            for (int a = 0; a < 3; ++a) {
+                h[2 * a] = float_to_half_dir(o[a], true);
+                h[2 * a + 1] = float_to_half_dir(o[3 + a], false);
+                h[6 + 2 * a] = float_to_half_dir(o[6 + a], true);
+                h[6 + 2 * a + 1] = float_to_half_dir(o[9 + a], false);
+            }
+            std::memcpy(&out.hnodes[k * 8], h, sizeof(h));          // 24 bytes = floats 0..5
+            out.hnodes[k * 8 + 6] = o[12];
+            out.hnodes[k * 8 + 7] = o[13];
+        }
     }
     // depth of the traversal tree (stack bound: one entry per level at most)
     {

@@ -25,6 +25,8 @@ inline int32_t leaf_code(int32_t prim_index, int32_t prim_type) { return -(2 * p
 
 struct Packed {
     std::vector<float> nodes;      // 16 floats per internal node
+    std::vector<float> hnodes;     // Guarded: the same nodes in 8 floats — boxes as binary16 rounded outward + 2 codes
+                                   // (what the kernel reads; layout in rt_accel.cpp)
     std::vector<float> spheres;    // 4 per sphere
     std::vector<int32_t> sphere_mat;
     std::vector<float> planes;     // 20 per plane
@@ -78,6 +80,10 @@ enum class TreeMode { Reference, Sah, Guarded, GuardedLeaves };
 
 // Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2.
 constexpr float kGuardGamma = 8.0f * 5.9604645e-8f;
+
+// binary16 helpers of the half-precision node table (exposed for the native test)
+float half_to_float(uint16_t h);
+uint16_t float_to_half_dir(float f, bool toward_minus_inf);
 
 // Returns "" on success, else a message (→ RT_ERR_INVALID_ARG).
 std::string pack_scene(const rt_scene_desc &desc, TreeMode mode, Packed &out);

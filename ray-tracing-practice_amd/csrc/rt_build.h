@@ -14,7 +14,8 @@
 namespace rtbuild {
 
 struct DeviceTree {
-    void *nodes = nullptr;      // float4[4 * num_internal], hipMalloc'ed; the caller frees it
+    void *nodes = nullptr;      // float4[4 * num_internal]: fp32 pair records; hipMalloc'ed, the caller frees it
+    void *hnodes = nullptr;     // float4[2 * num_internal]: the same records with binary16 planes; likewise
     int32_t num_internal = 0;
     int32_t root = 0;           // node code: >= 0 internal node, < 0 leaf code (single primitive)
     int32_t depth = 0;          // longest root-to-leaf path in internal nodes

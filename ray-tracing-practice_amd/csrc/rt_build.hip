@@ -2,6 +2,7 @@
 #include "rt_build.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -114,16 +115,29 @@ __global__ void refit_kernel(const Box *boxes, int32_t first, const uint32_t *va
     }
 }
 
-__device__ __forceinline__ void write_pair(float4 *nodes, int32_t k, const Box &b0, int32_t c0, const Box &b1, int32_t c1) {
-    // lo0.xyz hi0.xyz lo1.xyz hi1.xyz, codes (rt_accel.cpp, child-pair node table)
-    nodes[4 * k + 0] = make_float4(b0.v[0], b0.v[2], b0.v[4], b0.v[1]);
-    nodes[4 * k + 1] = make_float4(b0.v[3], b0.v[5], b1.v[0], b1.v[2]);
-    nodes[4 * k + 2] = make_float4(b1.v[4], b1.v[1], b1.v[3], b1.v[5]);
+// the child-pair records the guarded walk reads (rt_accel.cpp): fp32 planes (64 B, LDS-resident scenes) and the
+// same with 12 binary16 planes rounded OUTWARD (32 B, scenes read through L1/L2), two child codes each
+__device__ __forceinline__ void write_pair(float4 *nodes, float4 *hnodes, int32_t k, const Box &b0, int32_t c0, const Box &b1, int32_t c1) {
+    nodes[4 * k + 0] = make_float4(b0.v[0], b0.v[2], b0.v[4], b0.v[1]);      // lo0.xyz hi0.x
+    nodes[4 * k + 1] = make_float4(b0.v[3], b0.v[5], b1.v[0], b1.v[2]);      // hi0.yz lo1.xy
+    nodes[4 * k + 2] = make_float4(b1.v[4], b1.v[1], b1.v[3], b1.v[5]);      // lo1.z hi1.xyz
     nodes[4 * k + 3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.0f, 0.0f);
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    half8 a;
+    half4 b;
+    const __half h[12] = {__float2half_rd(b0.v[0]), __float2half_ru(b0.v[1]), __float2half_rd(b0.v[2]), __float2half_ru(b0.v[3]),
+                          __float2half_rd(b0.v[4]), __float2half_ru(b0.v[5]), __float2half_rd(b1.v[0]), __float2half_ru(b1.v[1]),
+                          __float2half_rd(b1.v[2]), __float2half_ru(b1.v[3]), __float2half_rd(b1.v[4]), __float2half_ru(b1.v[5])};
+    for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(_Float16, h[i]);
+    for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(_Float16, h[8 + i]);
+    const float2 bxy = __builtin_bit_cast(float2, b);
+    hnodes[2 * k + 0] = __builtin_bit_cast(float4, a);
+    hnodes[2 * k + 1] = make_float4(bxy.x, bxy.y, __int_as_float(c0), __int_as_float(c1));
 }
 
 __global__ void emit_kernel(const Box *boxes, const int32_t *codes, int32_t first, const uint32_t *vals, int32_t m, const int32_t *left,
-                            const int32_t *right, const Box *node_box, float4 *nodes) {
+                            const int32_t *right, const Box *node_box, float4 *nodes, float4 *hnodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m - 1) return;
     const int32_t lc = left[i], rc = right[i];
@@ -131,14 +145,14 @@ __global__ void emit_kernel(const Box *boxes, const int32_t *codes, int32_t firs
     const Box rb = rc >= 0 ? node_box[rc] : boxes[first + vals[~rc]];
     const int32_t c0 = lc >= 0 ? lc : codes[first + vals[~lc]];
     const int32_t c1 = rc >= 0 ? rc : codes[first + vals[~rc]];
-    write_pair(nodes, i, lb, c0, rb, c1);
+    write_pair(nodes, hnodes, i, lb, c0, rb, c1);
 }
 
 struct Summary { int32_t root, num_internal, depth, pad; };
 
 // one thread: the large primitives [0, num_large) become a chain above the LBVH root
 __global__ void chain_kernel(const Box *boxes, const int32_t *codes, int32_t num_large, int32_t m, const Box *node_box,
-                             const int32_t *height, float4 *nodes, Summary *out) {
+                             const int32_t *height, float4 *nodes, float4 *hnodes, Summary *out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     bool have = false;
     int32_t sub_code = 0, depth = 0, next = m >= 2 ? m - 1 : 0;
@@ -147,7 +161,7 @@ __global__ void chain_kernel(const Box *boxes, const int32_t *codes, int32_t num
     else if (m == 1) { have = true; sub_code = codes[num_large]; sub_box = boxes[num_large]; depth = 0; }
     for (int32_t j = 0; j < num_large; ++j) {
         if (!have) { have = true; sub_code = codes[j]; sub_box = boxes[j]; depth = 0; continue; }
-        write_pair(nodes, next, boxes[j], codes[j], sub_box, sub_code);
+        write_pair(nodes, hnodes, next, boxes[j], codes[j], sub_box, sub_code);
         sub_box = box_union(boxes[j], sub_box);
         sub_code = next++;
         depth++;
@@ -228,7 +242,7 @@ std::string build_lbvh(const float *leaf_boxes, const int32_t *leaf_codes, int32
     uint32_t *d_vals = nullptr, *d_vals_sorted = nullptr, *d_arrived = nullptr;
     void *d_temp = nullptr;
     size_t temp_bytes = 0;
-    float4 *d_nodes = nullptr;
+    float4 *d_nodes = nullptr, *d_hnodes = nullptr;
     Summary *d_summary = nullptr;
     Summary summary{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -252,6 +266,7 @@ std::string build_lbvh(const float *leaf_boxes, const int32_t *leaf_codes, int32
     BUILD_TRY(hipMalloc((void **)&d_arrived, 4 * (size_t)mm));
     BUILD_TRY(hipMalloc((void **)&d_node_box, sizeof(Box) * (size_t)mm));
     BUILD_TRY(hipMalloc((void **)&d_nodes, 64 * (size_t)(max_internal > 0 ? max_internal : 1)));
+    BUILD_TRY(hipMalloc((void **)&d_hnodes, 32 * (size_t)(max_internal > 0 ? max_internal : 1)));
     BUILD_TRY(hipMalloc((void **)&d_summary, sizeof(Summary)));
     if (m > 1) {
         BUILD_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys, d_keys_sorted, d_vals, d_vals_sorted, m, 0, 63));
@@ -269,9 +284,9 @@ std::string build_lbvh(const float *leaf_boxes, const int32_t *leaf_codes, int32
         hipLaunchKernelGGL(refit_kernel, dim3((m + threads - 1) / threads), dim3(threads), 0, 0, d_boxes, num_large, d_vals_sorted, m, d_left,
                            d_right, d_parent_i, d_parent_l, d_node_box, d_height, d_arrived);
         hipLaunchKernelGGL(emit_kernel, dim3((m + threads - 1) / threads), dim3(threads), 0, 0, d_boxes, d_codes, num_large, d_vals_sorted, m,
-                           d_left, d_right, d_node_box, d_nodes);
+                           d_left, d_right, d_node_box, d_nodes, d_hnodes);
     }
-    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, 0, d_boxes, d_codes, num_large, m, d_node_box, d_height, d_nodes, d_summary);
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, 0, d_boxes, d_codes, num_large, m, d_node_box, d_height, d_nodes, d_hnodes, d_summary);
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(hipEventRecord(ev1, 0));
     BUILD_TRY(hipEventSynchronize(ev1));
@@ -279,6 +294,8 @@ std::string build_lbvh(const float *leaf_boxes, const int32_t *leaf_codes, int32
     BUILD_TRY(hipMemcpy(&summary, d_summary, sizeof(summary), hipMemcpyDeviceToHost));
     out.nodes = d_nodes;
     d_nodes = nullptr;
+    out.hnodes = d_hnodes;
+    d_hnodes = nullptr;
     out.num_internal = summary.num_internal;
     out.root = summary.root;
     out.depth = summary.depth;
@@ -286,7 +303,7 @@ std::string build_lbvh(const float *leaf_boxes, const int32_t *leaf_codes, int32
 done:
     (void)hipFree(d_boxes); (void)hipFree(d_codes); (void)hipFree(d_keys); (void)hipFree(d_keys_sorted); (void)hipFree(d_vals);
     (void)hipFree(d_vals_sorted); (void)hipFree(d_left); (void)hipFree(d_right); (void)hipFree(d_parent_i); (void)hipFree(d_parent_l);
-    (void)hipFree(d_height); (void)hipFree(d_arrived); (void)hipFree(d_node_box); (void)hipFree(d_temp); (void)hipFree(d_nodes);
+    (void)hipFree(d_height); (void)hipFree(d_arrived); (void)hipFree(d_node_box); (void)hipFree(d_temp); (void)hipFree(d_nodes); (void)hipFree(d_hnodes);
     (void)hipFree(d_summary);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);

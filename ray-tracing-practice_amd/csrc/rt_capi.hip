@@ -69,6 +69,7 @@ struct rt_scene {
     int device = 0;
     float4 *tnodes = nullptr, *xnodes = nullptr;
     int32_t num_tnodes = 0, num_top = 0, num_top_pairs = 0;
+    float4 *hnodes = nullptr;       // pair records with binary16 planes (guarded walk from global memory)
     float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
@@ -146,7 +147,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.num_parts = s.num_parts;
     P.part = s.part;
     P.local_rows = rt_shard_rows(cam->image_height, shard);
-    P.nodes = sc->nodes; P.num_internal = sc->num_internal; P.root = sc->root;
+    P.nodes = sc->nodes; P.hnodes = sc->hnodes; P.num_internal = sc->num_internal; P.root = sc->root;
     P.tnodes = sc->tnodes; P.num_tnodes = sc->num_tnodes;
     P.xnodes = sc->xnodes; P.num_top = sc->num_top;
     P.spheres = sc->spheres; P.num_spheres = sc->num_spheres;
@@ -223,12 +224,16 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         const std::string berr = rtbuild::build_lbvh(pk.guard_leaf_boxes.data(), pk.guard_leaf_codes.data(), (int32_t)pk.guard_leaf_codes.size(), tree);
         if (!berr.empty()) return bail(fail(RT_ERR_HIP, "device BVH build: " + berr));
         sc->nodes = (float4 *)tree.nodes;
+        sc->hnodes = (float4 *)tree.hnodes;
         pk.num_internal = tree.num_internal;
         pk.root = tree.root;
         pk.max_depth = tree.depth;
         pk.num_top_pairs = 0;
         sc->build_ms = tree.build_ms;
-    } else if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
+    } else {
+        if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
+        if ((st = upload(pk.hnodes, (void **)&sc->hnodes)) != RT_OK) return bail(st);
+    }
     if ((st = upload(pk.tnodes, (void **)&sc->tnodes)) != RT_OK) return bail(st);
     sc->num_tnodes = pk.num_tnodes;
     if ((st = upload(pk.xnodes, (void **)&sc->xnodes)) != RT_OK) return bail(st);
@@ -260,7 +265,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     if (!sc) return RT_OK;
     (void)hipFree(sc->tnodes);
     (void)hipFree(sc->xnodes);
-    (void)hipFree(sc->nodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
+    (void)hipFree(sc->nodes); (void)hipFree(sc->hnodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
     (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
@@ -341,7 +346,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (!(dx * dx + dy * dy + dz * dz <= (double)sc->guard.origin_radius * sc->guard.origin_radius)) guarded = false;
     }
     if (guarded) {
-        const uint64_t table_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;
+        const uint64_t table_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;      // fp32 pair records when LDS-resident
         const int32_t want = sc->tree_depth + 1 > 2 ? sc->tree_depth + 1 : 2;       // never overflows
         const uint32_t per_level = rtk::kBlock * 4u;
         // tables in LDS when they leave room for a useful stack at full occupancy; else they are read
@@ -372,10 +377,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (!fast.in_lds && !env_int("RTP_NO_TREELET", 0)) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level;
-            const int64_t fit = budget > used ? (int64_t)((budget - used) / 64) : 0;
+            const int64_t fit = budget > used ? (int64_t)((budget - used) / 32) : 0;
             fast.num_top = (int32_t)(fit < sc->num_top_pairs ? fit : sc->num_top_pairs);
         }
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * 64) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * 32) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
         if (const int w = env_int("RTP_WGS_PER_CU", 0)) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
     }
     bool use_queue = false;

@@ -179,6 +179,29 @@ int main() {
                 ++leaves_seen;
             }
         CHECK(leaves_seen == hs.spheres.size());
+        // the table the kernel reads: the same boxes as binary16, each plane rounded outward, same child codes
+        CHECK(pk.hnodes.size() == (size_t)pk.num_internal * 8);
+        for (int32_t k = 0; k < pk.num_internal; ++k) {
+            const float *f = &pk.nodes[(size_t)k * 16];        // lo0.xyz hi0.xyz lo1.xyz hi1.xyz codes
+            uint16_t h[12];
+            std::memcpy(h, &pk.hnodes[(size_t)k * 8], sizeof(h));
+            for (int c = 0; c < 2; ++c)
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = rtaccel::half_to_float(h[6 * c + 2 * a]), hi = rtaccel::half_to_float(h[6 * c + 2 * a + 1]);
+                    CHECK(lo <= f[6 * c + a] && hi >= f[6 * c + 3 + a]);
+                    CHECK(f[6 * c + a] - lo <= 1.0f + 1e-3f * std::fabs(f[6 * c + a]));       // and by less than one binary16 step
+                    CHECK(hi - f[6 * c + 3 + a] <= 1.0f + 1e-3f * std::fabs(f[6 * c + 3 + a]));
+                }
+            CHECK(ibits(pk.hnodes[(size_t)k * 8 + 6]) == ibits(f[12]) && ibits(pk.hnodes[(size_t)k * 8 + 7]) == ibits(f[13]));
+        }
+        for (uint32_t b = 0; b < 0xffffff00u; b += 65521u) {       // directed rounding: a bracket, and a tight one
+            float x;
+            std::memcpy(&x, &b, 4);
+            if (std::isnan(x)) continue;
+            const float dn = rtaccel::half_to_float(rtaccel::float_to_half_dir(x, true)), up = rtaccel::half_to_float(rtaccel::float_to_half_dir(x, false));
+            CHECK(dn <= x && x <= up);
+            if (std::fabs(x) <= 65504.0f && std::fabs(x) >= 6.2e-5f) CHECK(up - dn <= std::fabs(x) * (1.0f / 1024.0f));
+        }
         // planes are eligible (their exact leaf boxes always travel as a table); a plane of unknown type is not
         rtp::HostScene with_plane;
         o.textured_floor_quad = true;
