@@ -313,7 +313,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
 
     const uint32_t waves = rtk::kBlock / rtk::kWave;
     const uint32_t pool_bytes = waves * 8u;                  // per-wave reserved work range
-    const uint64_t prim_f4 = (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 3 +
+    const uint64_t prim_f4 = (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 2 +      // LDS keeps 2 of the 3 material rows
                              ((uint64_t)P.num_spheres + 3) / 4;
 
     // ---- exact (threaded) walk: launch shape
