@@ -157,7 +157,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.tex_data = sc->tex_data; P.tex_info = sc->tex_info;
     P.queue = sc->queue;
     if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 pixels per call");
-    P.total_work = (uint32_t)P.local_rows * (uint32_t)P.width * 64u;      // upper bound; set per pass in rt_render
+    P.total_work = 0;      // set per pass in rt_render
     P.stats = sc->queue + kQueueStats;
     {
         const uint64_t pixels = (uint64_t)P.local_rows * (uint64_t)P.width;
