@@ -11,8 +11,14 @@ if os.environ.get('SCENE')=='default':      # the reference's `main --default` a
 else:
     W,H,SPP=1920,1080,int(os.environ.get('SPP',500))
     host=rb.HostScene.rtiow()
-    cam=rb.rtiow_camera(W,H,SPP,50)
-    label=f'S-rtiow {W}x{H} {SPP} spp 50 bounces'
+    view=os.environ.get('VIEW','headline')
+    if view=='low':      # skims the ground under the spheres: rays that graze sphere bottoms and box faces
+        cam=rb.make_camera(W,H,35.0,(-12.0,0.6,0.12),(4.0,0.0,0.2),(0.7,0.8,1.0),SPP,50)
+    elif view=='top':    # straight down from far above: every primary ray is a far-origin ray for the cluster
+        cam=rb.make_camera(W,H,12.0,(0.5,0.25,140.0),(0.0,0.0,0.0),(0.7,0.8,1.0),SPP,50)
+    else:
+        cam=rb.rtiow_camera(W,H,SPP,50)
+    label=f'S-rtiow {W}x{H} {SPP} spp 50 bounces, view {view}'
 dev=rb.DeviceScene(host,device=0)
 got,tm=dev.render_to_host(cam)
 print('gpu frame', tm.kernel_ms,'ms', flush=True)
@@ -27,4 +33,4 @@ for r0 in range(0,H,60):
 res={'config':label,'pixels':W*H,'samples':W*H*SPP,'pixels_differing':bad,'max_abs_diff':maxabs,
      'gpu_kernel_ms':tm.kernel_ms,'guarded_walk':int(tm.guarded),'flagged_samples':int(tm.flagged_samples),'oracle_seconds':time.time()-t,'frame_sha256':hashlib.sha256(got.tobytes()).hexdigest()}
 print(json.dumps(res))
-json.dump(res,open('gpurun_out/full_frame_parity_%s.json'%os.environ.get('SCENE','rtiow'),'w'),indent=1)
+json.dump(res,open('gpurun_out/full_frame_parity_%s%s.json'%(os.environ.get('SCENE','rtiow'),'' if os.environ.get('VIEW','headline')=='headline' else '_'+os.environ['VIEW']),'w'),indent=1)
