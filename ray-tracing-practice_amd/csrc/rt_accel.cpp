@@ -202,7 +202,7 @@ uint16_t float_to_half_dir(float f, bool toward_minus_inf) {
     return (uint16_t)((negative ? 0x8000u : 0u) | mag);
 }
 
-std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
+std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const float *camera_hint) {
     out = Packed{};
     if (d.num_spheres < 0 || d.num_planes < 0 || d.num_materials < 0 || d.num_nodes < 0 || d.num_textures < 0)
         return "negative element count";
@@ -427,7 +427,11 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                 r_all = std::max(r_all, std::sqrt(far2));
             }
             // ray origins: any point of a scene surface is within r_all of C; 25 % on top for the camera (checked per render)
-            const double origin_radius = 1.25 * r_all;
+            double origin_radius = 1.25 * r_all;
+            if (camera_hint) {      // a camera farther out than that: size the margins for it (rt_render re-packs on demand)
+                const float cam[3] = {camera_hint[0], camera_hint[1], camera_hint[2]};
+                origin_radius = std::max(origin_radius, 1.25 * dist(C, cam));
+            }
             for (int a = 0; a < 3; ++a) g.origin_center[a] = static_cast<float>(C[a]);
             g.origin_radius = static_cast<float>(origin_radius);
             // floor of every margin: the rounding of the walk's own box tests and of o + t d (a few ulps of the
@@ -470,6 +474,10 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out) {
                 const double reach_25 = std::sqrt(0.50 * r_min_small * r_min_small / double(kGuardGamma));
                 reach = std::max(reach, std::min(6.0 * rs, reach_25));
                 if (reach < 2.0 * rs) reach = 2.0 * rs;
+                if (camera_hint) {  // primary rays from a far camera: without this every one that heads for the cluster is flagged
+                    const float cam[3] = {camera_hint[0], camera_hint[1], camera_hint[2]};
+                    reach = std::max(reach, 1.25 * (dist(sc, cam) + rs));
+                }
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)
                     if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])

@@ -86,6 +86,8 @@ float half_to_float(uint16_t h);
 uint16_t float_to_half_dir(float f, bool toward_minus_inf);
 
 // Returns "" on success, else a message (→ RT_ERR_INVALID_ARG).
-std::string pack_scene(const rt_scene_desc &desc, TreeMode mode, Packed &out);
+// camera_hint (3 floats, optional): the guarded walk's margins are sized so that this ray origin is covered
+// too (a camera far outside the scene).
+std::string pack_scene(const rt_scene_desc &desc, TreeMode mode, Packed &out, const float *camera_hint = nullptr);
 
 }  // namespace rtaccel

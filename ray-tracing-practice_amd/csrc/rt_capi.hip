@@ -1,6 +1,7 @@
 // rt_capi.hip — implementation of the C ABI in include/rtp_amd.h on top of the gfx950 kernels.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +78,13 @@ struct rt_scene {
     float4 *slab = nullptr;         // per-sample radiance workspace of one pass, grown on demand
     size_t slab_float4s = 0;
     rtaccel::Packed::Guard guard;   // guarded-walk eligibility and parameters
+    // host copies of what the guard depends on: a camera outside the reach the margins were sized for makes
+    // rt_render re-pack the guarded walk's tree for it (reach only ever grows)
+    std::vector<rt_sphere> host_spheres;
+    std::vector<rt_plane> host_planes;
+    std::vector<rt_bvh_node> host_nodes;
+    bool device_built = false;
+    int repacks = 0;
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
@@ -178,6 +186,44 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     return RT_OK;
 }
 
+// Re-pack the guarded walk's tree with margins that cover ray origins at `cam` (see rt_render).
+rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream) {
+    rt_scene_desc d{};
+    d.spheres = sc->host_spheres.data(); d.num_spheres = (int32_t)sc->host_spheres.size();
+    d.planes = sc->host_planes.data(); d.num_planes = (int32_t)sc->host_planes.size();
+    d.nodes = sc->host_nodes.data(); d.num_nodes = (int32_t)sc->host_nodes.size();
+    // materials and textures do not enter the tree: one dummy material satisfies the index validation
+    std::vector<rt_sphere> spheres(sc->host_spheres);
+    std::vector<rt_plane> planes(sc->host_planes);
+    for (rt_sphere &s : spheres) s.material_idx = 0;
+    for (rt_plane &p : planes) p.material_idx = 0;
+    rt_material dummy{};
+    d.spheres = spheres.data();
+    d.planes = planes.data();
+    d.materials = &dummy; d.num_materials = 1;
+    rtaccel::Packed pk;
+    const std::string err = rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk, cam);
+    if (!err.empty()) return fail(RT_ERR_INVALID_ARG, "re-pack for a far camera: " + err);
+    if (!pk.guard.ok) return fail(RT_ERR_INVALID_ARG, "re-pack for a far camera: " + pk.guard.reason);
+    HIP_TRY(hipStreamSynchronize(stream));          // the old tables may still be in use on this stream
+    float4 *nodes = nullptr, *hnodes = nullptr, *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;
+    rt_status st = RT_OK;
+    if ((st = upload(pk.nodes, (void **)&nodes)) != RT_OK || (st = upload(pk.hnodes, (void **)&hnodes)) != RT_OK ||
+        (st = upload(pk.leaf_boxes, (void **)&leaf_boxes)) != RT_OK || (st = upload(pk.plane_leaf_boxes, (void **)&plane_leaf_boxes)) != RT_OK) {
+        (void)hipFree(nodes); (void)hipFree(hnodes); (void)hipFree(leaf_boxes); (void)hipFree(plane_leaf_boxes);
+        return st;
+    }
+    (void)hipFree(sc->nodes); (void)hipFree(sc->hnodes); (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes);
+    sc->nodes = nodes; sc->hnodes = hnodes; sc->leaf_boxes = leaf_boxes; sc->plane_leaf_boxes = plane_leaf_boxes;
+    sc->num_internal = pk.num_internal;
+    sc->num_top_pairs = pk.num_top_pairs;
+    sc->root = pk.root;
+    sc->tree_depth = pk.max_depth;
+    sc->guard = pk.guard;
+    sc->repacks++;
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -247,6 +293,12 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if ((st = upload(pk.leaf_boxes, (void **)&sc->leaf_boxes)) != RT_OK) return bail(st);
     if ((st = upload(pk.plane_leaf_boxes, (void **)&sc->plane_leaf_boxes)) != RT_OK) return bail(st);
     sc->guard = pk.guard;
+    if (pk.guard.ok) {
+        sc->host_spheres.assign(desc->spheres, desc->spheres + desc->num_spheres);
+        sc->host_planes.assign(desc->planes, desc->planes + desc->num_planes);
+        sc->host_nodes.assign(desc->nodes, desc->nodes + desc->num_nodes);
+        sc->device_built = device_build;
+    }
     if (hipMalloc((void **)&sc->queue, kQueueWords * 4) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(queue) failed"));
     if (hipEventCreate(&sc->ev_start) != hipSuccess || hipEventCreate(&sc->ev_stop) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
@@ -340,10 +392,24 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0 && guarded_wanted((int64_t)P.num_spheres + P.num_planes);
     Shape fast{};
     if (guarded) {
-        // the margins were sized for ray origins within origin_radius of origin_center: so must the camera be
-        const float *q = sc->guard.origin_center;
-        const double dx = (double)cam->origin.e[0] - q[0], dy = (double)cam->origin.e[1] - q[1], dz = (double)cam->origin.e[2] - q[2];
-        if (!(dx * dx + dy * dy + dz * dz <= (double)sc->guard.origin_radius * sc->guard.origin_radius)) guarded = false;
+        // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
+        // spheres for origins within sqrt(d0_sq) of their cluster: a camera outside either gets the tree re-packed
+        // with margins for where it is (once per growth of the reach; the exact walk's tables do not change).
+        auto outside = [&](const float *c, double radius_sq) {
+            const double dx = (double)cam->origin.e[0] - c[0], dy = (double)cam->origin.e[1] - c[1], dz = (double)cam->origin.e[2] - c[2];
+            return !(dx * dx + dy * dy + dz * dz <= radius_sq);
+        };
+        const bool far_cam = outside(sc->guard.origin_center, (double)sc->guard.origin_radius * sc->guard.origin_radius) ||
+                             (sc->guard.num_small > 0 && outside(sc->guard.center, (double)sc->guard.d0_sq));
+        if (far_cam && std::isfinite(cam->origin.e[0]) && std::isfinite(cam->origin.e[1]) && std::isfinite(cam->origin.e[2]) &&
+            !env_int("RTP_NO_REPACK", 0)) {
+            st = repack_for_camera(sc, cam->origin.e, stream);
+            if (st != RT_OK) return st;
+            st = fill_params(sc, cam, shard, P);       // table pointers and guard parameters changed
+            if (st != RT_OK) return st;
+            P.fb = d_fb_sum;
+        }
+        if (outside(sc->guard.origin_center, (double)sc->guard.origin_radius * sc->guard.origin_radius)) guarded = false;
     }
     if (guarded) {
         const uint64_t table_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;      // fp32 pair records when LDS-resident

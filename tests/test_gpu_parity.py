@@ -422,9 +422,21 @@ def test_guarded_walk_far_camera_and_ties():
     host = rb.HostScene.rtiow()
     dev = rb.DeviceScene(host, device=0)
     cam = rb.make_camera(160, 90, 3.0, (400.0, 90.0, 60.0), (0, 0, 0), (0.7, 0.8, 1.0), 4, 50)
-    fb, t = dev.render_to_host(cam)
-    assert t.guarded == 1 and t.flagged_samples > 0
-    assert_same_frame(fb, ob.render(host, cam, threads=8), "far camera")
+    want = ob.render(host, cam, threads=8)
+    try:
+        os.environ["RTP_NO_REPACK"] = "1"           # margins as packed: the far-origin test has to catch the primary rays
+        fb, t = dev.render_to_host(cam)
+        assert t.guarded == 1 and t.flagged_samples > 1000
+        assert_same_frame(fb, want, "far camera, far-origin test")
+    finally:
+        os.environ.pop("RTP_NO_REPACK", None)
+    fb, t2 = dev.render_to_host(cam)                # default: the tree is re-packed with margins for this camera
+    assert t2.guarded == 1 and t2.flagged_samples < t.flagged_samples // 4
+    assert_same_frame(fb, want, "far camera, re-packed tree")
+    near = rb.rtiow_camera(160, 90, 4, 50)           # and the re-packed tree serves the usual camera as well
+    fb, t3 = dev.render_to_host(near)
+    assert t3.guarded == 1
+    assert_same_frame(fb, ob.render(host, near, threads=8), "near camera after a re-pack")
 
     mats = [_material(0, albedo=(0.8, 0.3, 0.3)), _material(0, albedo=(0.2, 0.9, 0.3)), _material(1, albedo=(0.9, 0.9, 0.9), fuzz=0.1),
             _material(2, ir=1.5)]
