@@ -8,7 +8,7 @@ cam.samples_per_pixel = int(os.environ.get("SPP", "100"))
 dev = rb.DeviceScene(host, 0)
 n = cam.image_width * cam.image_height * cam.samples_per_pixel
 print("spheres", host.desc.num_spheres, "planes", host.desc.num_planes, "nodes", host.desc.num_nodes, "reason", repr(dev.guard_reason()))
-for env in ({}, {"RTP_WGS_PER_CU": "1"}, {"RTP_STACK_LEVELS": "3"}, {"RTP_TRAVERSAL": "threaded"}):
+for env in ({}, {"RTP_TRAVERSAL": "guarded"}, {"RTP_TRAVERSAL": "threaded"}):
     for k in ("RTP_WGS_PER_CU", "RTP_STACK_LEVELS", "RTP_TRAVERSAL"):
         os.environ.pop(k, None)
     os.environ.update(env)
