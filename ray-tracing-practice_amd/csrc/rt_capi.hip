@@ -585,6 +585,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             per = per < 1 ? 1 : (per > 8 ? 8 : per);
             if (const int forced = env_int("RTP_CHUNK", 0)) per = (uint64_t)(forced > 0 ? forced : 1);
             P.chunk = (uint32_t)(64u * per);
+            P.taper_shift = 1;                      // remaining / (2 x waves), rounded to a power of two
+            while (((uint64_t)1 << P.taper_shift) < 2 * waves_total) ++P.taper_shift;
+            if (env_int("RTP_NO_TAPER", 0)) P.taper_shift = 0;
         }
         if (use_queue) {
             P.stack_levels = 0;
@@ -609,6 +612,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             R.work_count = sc->queue + kQueueFlag + pass;
             R.work_cap = P.flag_cap;
             R.chunk = 64u;                     // a short list: finest granularity
+            R.taper_shift = 0;
             HIP_TRY(launch_exact(R, grid_for(exact)));
         } else {
             HIP_TRY(launch_exact(P, wgs));
