@@ -78,7 +78,8 @@ struct Packed {
 // guard_leaf_boxes / guard_leaf_codes for a device-side builder (rt_build.h).
 enum class TreeMode { Reference, Sah, Guarded, GuardedLeaves };
 
-// Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2.
+// Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2: 16x the largest
+// error observed; the sum of every rounding's worst case would be ~21 x 2^-24.
 constexpr float kGuardGamma = 8.0f * 5.9604645e-8f;
 
 // binary16 helpers of the half-precision node table (exposed for the native test)
