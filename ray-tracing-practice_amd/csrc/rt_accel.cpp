@@ -362,6 +362,10 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
         Packed::Guard &g = out.guard;
         std::string why;
         const double u = 5.9604645e-8;       // 2^-24
+        // error budget of hit_sphere's discriminant, in units of |oc|^2 |d|^2: scenes small enough for LDS get the
+        // term-by-term worst-case bound (it costs them little); big ones, whose margins are already large, a margin
+        // of 16x the largest error observed
+        const double gamma = (int64_t)d.num_spheres + d.num_planes <= kGuardBoundBelow ? double(kGuardGammaBound) : double(kGuardGamma);
         std::vector<int32_t> leaf_of_sphere(static_cast<size_t>(d.num_spheres), -1), leaf_of_plane(static_cast<size_t>(d.num_planes), -1);
         if (leaves.empty()) why = "no primitives";
         else if (d.num_spheres >= (1 << 24) || d.num_planes >= (1 << 24)) why = "too many primitives";
@@ -449,7 +453,7 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
                 if (leaf_of_sphere[static_cast<size_t>(i)] < 0) continue;
                 const rt_sphere &s = d.spheres[i];
                 const double reach = dist(C, s.center.e) + origin_radius;
-                const double e = double(kGuardGamma) * reach * reach / (2.0 * s.radius);
+                const double e = gamma * reach * reach / (2.0 * s.radius);
                 if (e <= 0.05 * s.radius) {
                     large[static_cast<size_t>(i)] = 1;
                     eps[static_cast<size_t>(i)] = e;
@@ -468,11 +472,11 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
                         rs = std::max(rs, dist(sc, d.spheres[i].center.e) + d.spheres[i].radius);
                 // origins within d0 of the centre: margin 4 % of the smallest radius, but never less than the
                 // cluster itself (paths start on its surfaces)
-                // … and up to 25 % of it where that buys origins out to 5 cluster radii from the centre (a camera
+                // … and up to 25 % of it where that buys origins out to 3 cluster radii from the centre (a camera
                 // orbiting a compact scene of tiny spheres must not make every primary ray a far-origin ray)
-                double reach = std::sqrt(0.08 * r_min_small * r_min_small / double(kGuardGamma));
-                const double reach_25 = std::sqrt(0.50 * r_min_small * r_min_small / double(kGuardGamma));
-                reach = std::max(reach, std::min(6.0 * rs, reach_25));
+                double reach = std::sqrt(0.08 * r_min_small * r_min_small / gamma);
+                const double reach_25 = std::sqrt(0.50 * r_min_small * r_min_small / gamma);
+                reach = std::max(reach, std::min(4.0 * rs, reach_25));
                 if (reach < 2.0 * rs) reach = 2.0 * rs;
                 if (camera_hint) {  // primary rays from a far camera: without this every one that heads for the cluster is flagged
                     const float cam[3] = {camera_hint[0], camera_hint[1], camera_hint[2]};
@@ -481,11 +485,11 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)
                     if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
-                        eps[static_cast<size_t>(i)] = double(kGuardGamma) * reach * reach / (2.0 * d.spheres[i].radius);
+                        eps[static_cast<size_t>(i)] = gamma * reach * reach / (2.0 * d.spheres[i].radius);
                 for (int a = 0; a < 3; ++a) g.center[a] = static_cast<float>(sc[a]);
                 g.d0_sq = static_cast<float>(d0 * d0 * (1.0 - 1e-6));
                 g.cluster_radius = static_cast<float>(rs * (1.0 + 1e-6));
-                g.far_k = static_cast<float>(double(kGuardGamma) / (2.0 * r_min_small) * (1.0 + 1e-6));
+                g.far_k = static_cast<float>(gamma / (2.0 * r_min_small) * (1.0 + 1e-6));
                 for (int i = 0; i < d.num_spheres; ++i) {
                     if (leaf_of_sphere[static_cast<size_t>(i)] < 0 || large[static_cast<size_t>(i)]) continue;
                     const float *b = d.nodes[leaf_of_sphere[static_cast<size_t>(i)]].box;

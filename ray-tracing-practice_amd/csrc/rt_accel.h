@@ -81,6 +81,9 @@ enum class TreeMode { Reference, Sah, Guarded, GuardedLeaves };
 // Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2: 16x the largest
 // error observed; the sum of every rounding's worst case would be ~21 x 2^-24.
 constexpr float kGuardGamma = 8.0f * 5.9604645e-8f;
+// … and the bound: scenes of at most kGuardBoundBelow primitives use it.
+constexpr float kGuardGammaBound = 24.0f * 5.9604645e-8f;
+constexpr int64_t kGuardBoundBelow = 4096;
 
 // binary16 helpers of the half-precision node table (exposed for the native test)
 float half_to_float(uint16_t h);

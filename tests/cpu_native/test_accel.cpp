@@ -170,7 +170,7 @@ int main() {
                 const double r = sp.radius;
                 // small spheres: gamma * reach^2 / (2 r) with reach = d0 + cluster radius (4 % of the smallest radius)
                 const double reach = std::sqrt((double)pk.guard.d0_sq) + pk.guard.cluster_radius;
-                const double margin = idx == 0 ? 1e-4 : 0.99 * rtaccel::kGuardGamma * reach * reach / (2 * r);
+                const double margin = idx == 0 ? 1e-4 : 0.99 * rtaccel::kGuardGammaBound * reach * reach / (2 * r);   // a small scene: the bound
                 if (idx != 0 && r < 0.25) CHECK(margin > 0.035 * r);
                 for (int a = 0; a < 3; ++a) {
                     CHECK(lo[a] <= sp.center.e[a] - r - margin && hi[a] >= sp.center.e[a] + r + margin);
