@@ -482,6 +482,8 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
                     const float cam[3] = {camera_hint[0], camera_hint[1], camera_hint[2]};
                     reach = std::max(reach, 1.25 * (dist(sc, cam) + rs));
                 }
+                // tiny spheres scattered over a large volume: the margin (∝ reach^2 / r) swallows the tree
+                if (gamma * reach * reach / (2.0 * r_min_small) > 64.0 * r_min_small) why = "margins exceed 64 radii for the smallest spheres";
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)
                     if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
@@ -525,7 +527,7 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
                     if (lb[2 * a] != s.center.e[a] - s.radius || lb[2 * a + 1] != s.center.e[a] + s.radius) derivable = false;
             }
             if (derivable && !getenv("RTP_GUARD_TABLE")) out.leaf_boxes.clear();
-            g.ok = true;
+            g.ok = why.empty();
         }
         g.reason = why;
     }

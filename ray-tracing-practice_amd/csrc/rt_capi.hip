@@ -85,6 +85,8 @@ struct rt_scene {
     std::vector<rt_bvh_node> host_nodes;
     bool device_built = false;
     int repacks = 0;
+    bool repack_refused = false;    // a re-pack for a far camera was not eligible: do not try again
+    bool guard_paused = false;      // a frame flagged more than 2 % of its samples: later frames use the exact walk
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
@@ -94,6 +96,7 @@ struct rt_scene {
     int timed_passes = 0;
     rt_timing last{};
     int last_passes = 0;
+    uint64_t last_samples = 0;
     bool timed = false;
     int num_cus = 0;
     float build_ms = 0.0f;          // device BVH build time (RTP_BUILD=device), else 0
@@ -205,7 +208,10 @@ rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream
     rtaccel::Packed pk;
     const std::string err = rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk, cam);
     if (!err.empty()) return fail(RT_ERR_INVALID_ARG, "re-pack for a far camera: " + err);
-    if (!pk.guard.ok) return fail(RT_ERR_INVALID_ARG, "re-pack for a far camera: " + pk.guard.reason);
+    if (!pk.guard.ok) {          // margins for that distance would swallow the tree: such cameras get the exact walk
+        sc->repack_refused = true;
+        return RT_OK;
+    }
     HIP_TRY(hipStreamSynchronize(stream));          // the old tables may still be in use on this stream
     float4 *nodes = nullptr, *hnodes = nullptr, *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;
     rt_status st = RT_OK;
@@ -390,7 +396,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     }
 
     // ---- guarded near-first walk: only for eligible scenes that fit LDS with a useful stack
-    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0 && guarded_wanted((int64_t)P.num_spheres + P.num_planes);
+    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0 && guarded_wanted((int64_t)P.num_spheres + P.num_planes) &&
+                   !(sc->guard_paused && !env_int("RTP_GUARD_KEEP", 0));
     Shape fast{};
     if (guarded) {
         // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
@@ -402,8 +409,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         };
         const bool far_cam = outside(sc->guard.origin_center, (double)sc->guard.origin_radius * sc->guard.origin_radius) ||
                              (sc->guard.num_small > 0 && outside(sc->guard.center, (double)sc->guard.d0_sq));
-        if (far_cam && std::isfinite(cam->origin.e[0]) && std::isfinite(cam->origin.e[1]) && std::isfinite(cam->origin.e[2]) &&
-            !env_int("RTP_NO_REPACK", 0)) {
+        if (far_cam && !sc->repack_refused && std::isfinite(cam->origin.e[0]) && std::isfinite(cam->origin.e[1]) &&
+            std::isfinite(cam->origin.e[2]) && !env_int("RTP_NO_REPACK", 0)) {
             st = repack_for_camera(sc, cam->origin.e, stream);
             if (st != RT_OK) return st;
             st = fill_params(sc, cam, shard, P);       // table pointers and guard parameters changed
@@ -411,6 +418,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             P.fb = d_fb_sum;
         }
         if (outside(sc->guard.origin_center, (double)sc->guard.origin_radius * sc->guard.origin_radius)) guarded = false;
+        if (sc->repack_refused && sc->guard.num_small > 0 && outside(sc->guard.center, (double)sc->guard.d0_sq)) guarded = false;
     }
     if (guarded) {
         const uint64_t table_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;      // fp32 pair records when LDS-resident
@@ -637,6 +645,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last.trace_launches = (uint32_t)passes;
     sc->last.guarded = guarded ? 1u : 0u;
     sc->last_passes = passes;
+    sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);
     if (timing) *timing = sc->last;
     return RT_OK;
@@ -668,6 +677,9 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
             uint64_t total = 0;
             for (uint32_t c : counts) total += c;
             sc->last.flagged_samples = total;
+            // a scene the guarded walk keeps handing back (dense overlaps, a camera inside a sphere, …) is cheaper on the
+            // exact walk alone: later frames of this handle use it
+            if (total * 50 > sc->last_samples) sc->guard_paused = true;       // more than 2 % of the samples
         }
         uint32_t abort_code = 0;
         HIP_TRY(hipMemcpy(&abort_code, sc->queue + kQueueStats + 15, 4, hipMemcpyDeviceToHost));
