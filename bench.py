@@ -7,34 +7,203 @@ configs[2] (the configuration the metric is quoted on).  Scene and CameraData ar
 the host mirror and are resident on the GPU before the timed region; the timed region is
 K x [rt_render (+ for N > 1 one RCCL gather of the row bands to rank 0)].
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The frame's rows are
-sharded in interleaved 8-row bands, every rank renders its rows of the SAME frame and one
-dist.gather assembles the frame on rank 0 — total work is fixed, so "scaling" is "strong".
+Process layout
+  * `python bench.py --gpus N` with no WORLD_SIZE in the environment is a LAUNCHER: it never touches
+    the GPU itself, starts N worker processes (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set,
+    rendezvous on 127.0.0.1), relays rank 0's JSON line and exits non-zero if any worker fails.
+    At N = 1 it also runs three short `rocprofv3 --pmc` passes of one frame (VALU counters, FETCH_SIZE,
+    WRITE_SIZE — separate passes, no tracing) and folds the measured VALU utilisation and HBM traffic
+    of the dominant kernel into the line's `roofline` block.
+  * with WORLD_SIZE set (the driver's `python -m torch.distributed.run … bench.py --gpus N`, or a
+    worker of the launcher above) the process is ONE RANK: torch.distributed over RCCL ("nccl").
 
-Prints ONE JSON line on rank 0.
+N > 1: the frame's rows are sharded in interleaved 8-row bands, every rank renders its rows of the
+SAME frame and one dist.gather assembles the frame on rank 0 — total work is fixed, so "scaling"
+is "strong".
+
+Prints ONE JSON line (rank 0 / the launcher).
 """
 import argparse
-import ctypes as C
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracing-practice_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import frame_parallel as fp  # noqa: E402
-import rtp_bindings as rb  # noqa: E402
-
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 500, 50
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-operations per second
+# (= the 157.3 TFLOPS fp32 vector peak at 2 flops per fused lane-op)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+NUM_SIMDS = 1024
+
+PMC_VALU = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+            "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]
 
 
+# ------------------------------------------------------------------------------------------------
+# launcher (parent): no torch.cuda, no rt_* call in this process
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker_cmd(args, extra=()):
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--spp", str(args.spp)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.dry_run:
+        cmd.append("--dry-run")
+    return cmd + list(extra)
+
+
+def _last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def _pmc_pass(args, counters, tag):
+    """One `rocprofv3 --pmc` pass (counters only: never combined with tracing) around ONE frame of the
+    same workload; returns {kernel name: {counter: mean per launch}} or None."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    out_dir = tempfile.mkdtemp(prefix=f"rtp_pmc_{tag}_", dir="/tmp")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", TMPDIR="/tmp", RTP_BENCH_PMC_CHILD="1")
+    # the program itself after `--`: the profiler's library has initialised the GPU before it starts
+    cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--spp", str(args.spp), "--no-cpu-baseline"]
+    try:
+        res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=args.pmc_timeout)
+    except (subprocess.TimeoutExpired, OSError):
+        return None
+    if res.returncode != 0:
+        sys.stderr.write(f"[bench] rocprofv3 pass '{tag}' failed ({res.returncode}): {res.stderr[-400:]}\n")
+        return None
+    files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        return None
+    acc, cnt = {}, {}
+    for row in csv.DictReader(open(files[0])):
+        key = (row["Kernel_Name"], row["Counter_Name"])
+        acc[key] = acc.get(key, 0.0) + float(row["Counter_Value"])
+        cnt[key] = cnt.get(key, 0) + 1
+    keep = os.environ.get("RTP_BENCH_PMC_KEEP")      # tools/profile_bench.sh: copy the raw CSV for profiles/
+    if keep:
+        os.makedirs(keep, exist_ok=True)
+        shutil.copy(files[0], os.path.join(keep, f"pmc_{tag}.csv"))
+    shutil.rmtree(out_dir, ignore_errors=True)
+    per = {}
+    for (kn, cn), v in acc.items():
+        per.setdefault(kn, {})[cn] = v / cnt[(kn, cn)]
+        per[kn]["_launches"] = cnt[(kn, cn)]
+    return per
+
+
+def _match_kernel(per, name):
+    """Counter rows of the kernel whose (possibly truncated) name matches `name`."""
+    if not per:
+        return None
+    for kn, vals in per.items():
+        if kn.startswith(name) or name.startswith(kn) or name in kn:
+            return vals
+    return None
+
+
+def _fold_pmc(out, args):
+    """N = 1: measure the dominant kernel's VALU utilisation and HBM traffic in THIS run."""
+    roof = out.get("roofline")
+    if not roof:
+        return
+    kernel = roof.get("kernel", "render_kernel")
+    short = kernel.split("(")[0]
+    valu = _match_kernel(_pmc_pass(args, PMC_VALU, "valu"), short)
+    fetch = _match_kernel(_pmc_pass(args, ["FETCH_SIZE"], "fetch"), short)
+    write = _match_kernel(_pmc_pass(args, ["WRITE_SIZE"], "write"), short)
+    if valu and valu.get("GRBM_GUI_ACTIVE") and valu.get("SQ_ACTIVE_INST_VALU"):
+        cycles = valu["GRBM_GUI_ACTIVE"] / 8.0                         # summed over the 8 XCDs
+        issue = 2.0 * valu["SQ_INSTS_VALU"] / (NUM_SIMDS * cycles)     # a wave64 VALU instruction holds its SIMD-32 for 2 cycles
+        lanes = valu["SQ_THREAD_CYCLES_VALU"] / (64.0 * valu["SQ_ACTIVE_INST_VALU"])
+        frac = issue * lanes
+        roof.update({
+            "bound": "valu", "frac": round(frac, 4), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "Tlane-op/s",
+            "achieved": round(frac * VALU_PEAK_TLANEOPS, 2),
+            "valu_issue_utilisation": round(issue, 4), "valu_lane_utilisation": round(lanes, 4),
+            "valu_wave_instructions_per_launch": valu["SQ_INSTS_VALU"],
+            "valu_wave_instructions_per_sample": round(valu["SQ_INSTS_VALU"] / max(roof.get("samples_per_launch", 1), 1), 2),
+            "wave_time_split": {"issuing": round(valu["SQ_ACTIVE_INST_ANY"] / valu["SQ_WAVE_CYCLES"], 3),
+                                "s_waitcnt": round(valu["SQ_WAIT_ANY"] / valu["SQ_WAVE_CYCLES"], 3),
+                                "issue_stalled": round(valu["SQ_WAIT_INST_ANY"] / valu["SQ_WAVE_CYCLES"], 3)},
+            "profiled_clock_ghz": None,
+            "source": "rocprofv3 --pmc passes run by this bench invocation (one frame each, counters only)",
+            "formula": "frac = issue x lanes; issue = 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8); lanes = "
+                       "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
+        })
+    else:
+        roof["source"] = "VALU counters unavailable in this run (rocprofv3 pass failed or missing); see profiles/"
+    if fetch and write and "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
+        # MI355X_MICROARCH.md §HBM: counters in KiB; gfx950 reports half of a wide coalesced read
+        traffic = (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0
+        roof["traffic"] = int(traffic)
+        launch_s = roof["launch_ms"] * 1e-3
+        roof["hbm_measured"] = {"bytes_per_launch": int(traffic), "GBps": round(traffic / launch_s / 1e9, 1),
+                                "frac_of_peak": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                                "fetch_kib": fetch["FETCH_SIZE"], "write_kib": write["WRITE_SIZE"]}
+
+
+def launcher(args):
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(_worker_cmd(args), env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        sys.stderr.write(f"[bench] worker exit codes {codes}\n")
+        sys.stdout.write(out0 or "")
+        return 1
+    out = _last_json_line(out0 or "")
+    if out is None:
+        sys.stderr.write("[bench] rank 0 printed no JSON line\n")
+        sys.stdout.write(out0 or "")
+        return 1
+    if out.get("n_gpus") != n:
+        sys.stderr.write(f"[bench] rank 0 reports n_gpus={out.get('n_gpus')} but --gpus {n}\n")
+        return 1
+    if n == 1 and not args.no_pmc and not args.dry_run:
+        _fold_pmc(out, args)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# worker: one rank
+# ------------------------------------------------------------------------------------------------
 def host_threads():
     """Host cores this process may use, capped at the 16-core share of a one-GPU box."""
     try:
@@ -50,7 +219,9 @@ def cpu_baseline(host, threads, budget_s=12.0, frame=None, gpu_cam=None):
     Also returns the traversal statistics that price the algorithmic bytes per sample and, since
     the CPU path is running anyway, renders two rows at the timed configuration's full spp and
     compares them bit for bit with the GPU frame that was just timed."""
+    import numpy as np
     import oracle_bindings as ob   # the checker; never on the product path
+    import rtp_bindings as rb
     # single thread (what the reference's own CPU path uses): a 1080/40-row slice at 1 spp
     cam1 = rb.rtiow_camera(WIDTH, HEIGHT, 1, DEPTH)
     rows = list(range(0, HEIGHT, 40))
@@ -85,18 +256,52 @@ def cpu_baseline(host, threads, budget_s=12.0, frame=None, gpu_cam=None):
     }, st
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (invalidates the headline)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def dry_run_worker(args, world, rank):
+    """No GPU: the N-rank control flow only (rendezvous, band arithmetic, one gather, world-size check).
+    Every rank fills its rows with a function of (row, column) and rank 0 checks the assembled frame.
+    The line it prints carries no measurement."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import frame_parallel as fp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    band = fp.DEFAULT_BAND_ROWS
+    rows = fp.shard_row_indices(HEIGHT, band, world, rank)
+    pattern = lambda r: (r[:, None, None] * 4096.0 + np.arange(WIDTH)[None, :, None] + np.arange(3)[None, None, :] * 0.25).astype(np.float32)
+    local = torch.from_numpy(pattern(rows))
+    frame = fp.gather_frame(local, HEIGHT, band) if world > 1 else local
+    if rank == 0:
+        ok = bool(np.array_equal(frame.numpy(), pattern(np.arange(HEIGHT))))
+        print(json.dumps({"metric": "Msamples/sec (pixels x spp / s), path-traced frame", "value": None, "unit": "Msamples/s",
+                          "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True, "backend": "gloo",
+                          "world_size_seen_by_collective": dist.get_world_size() if world > 1 else 1,
+                          "assembled_frame_ok": ok, "scaling": "strong"}), flush=True)
+        if not ok:
+            raise SystemExit(2)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def worker(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run_worker(args, world, rank)
+
+    import ctypes as C
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import frame_parallel as fp
+    import rtp_bindings as rb
+
     backend = os.environ.get("RTP_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 flow on one GPU
     if world > 1 and backend != "nccl":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -105,9 +310,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device(f"cuda:{local_rank}"))
+                                    device_id=torch.device(f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}"))
         except TypeError:       # older torch: no device_id keyword
             dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world > 1:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     local_rank %= torch.cuda.device_count()          # (rehearsals may put several ranks on one GPU)
@@ -174,6 +381,8 @@ def main():
             "config": {"workload": f"S-rtiow random-sphere scene (486 spheres, 971 BVH nodes, seed 12345), {WIDTH}x{HEIGHT}, "
                                    f"{args.spp} spp, {DEPTH} bounces, background (0.7,0.8,1.0)",
                        "parallelism": f"row-band shard x{world} + 1 gather" if world > 1 else "single GPU",
+                       "collective_backend": (backend if world > 1 else None),
+                       "world_size_seen_by_collective": (dist.get_world_size() if world > 1 else 1),
                        "traversal": ("guarded near-first walk + exact re-walk of flagged samples" if guarded and guarded[0]
                                      else "reference-order (threaded) walk")},
         }
@@ -188,44 +397,41 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             base, st = cpu_baseline(host, host_threads(), frame=frame.detach().cpu().numpy(), gpu_cam=cam)
             out["cpu_baseline"] = base
-        # roofline of the dominant (only) kernel: algorithmic bytes per launch / mean launch time
+        # ---- roofline of the dominant kernel (the trace launch) ------------------------------------
+        # The path is VALU-bound (scene tables live in LDS); the launcher adds the measured VALU issue x lane
+        # utilisation (`bound`, `frac`, `achieved`, `peak`) and the PMC HBM bytes (`traffic`) to this block.
         bytes_per_sample = st.bytes_per_sample(args.spp) if st is not None else 5790.0   # SURVEY.md §8(d) if not re-counted
         local_samples = local_rows * WIDTH * args.spp
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         tr_ms = float(np.mean(trace_ms)) if trace_ms else float("nan")
         n_launch = int(launches[0]) if launches else 0
-        # one frame = n_launch launches of the trace kernel (a pass of samples per pixel each);
-        # achieved = algorithmic bytes of one launch / its mean duration
         launch_ms = tr_ms / max(n_launch, 1)
-        achieved = bytes_per_sample * (local_samples / max(n_launch, 1)) / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.spp == SPP:
-            try:
-                tj = json.load(open(tpath))       # measured for one launch shape: only quoted when this run has it
-                traffic = tj.get("bytes_per_trace_launch") if tj.get("trace_launches_per_frame") == n_launch else None
-            except Exception:
-                traffic = None
-        valu = None
+        alg = bytes_per_sample * (local_samples / max(n_launch, 1)) / (launch_ms * 1e-3) / 1e9
+        committed = None
         vpath = os.path.join(ROOT, "profiles", "valu_util.json")
-        if os.path.exists(vpath) and world == 1 and args.spp == SPP:
+        if os.path.exists(vpath):
             try:
                 v = json.load(open(vpath))
-                valu = {k: v[k] for k in ("valu_issue_utilisation", "valu_lane_utilisation", "valu_roofline_frac")}
+                committed = {k: v[k] for k in ("valu_issue_utilisation", "valu_lane_utilisation", "valu_roofline_frac")}
             except Exception:
-                valu = None
+                committed = None
         out["roofline"] = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "rtk::render_kernel<true,false>" if guarded and guarded[0] else "rtk::render_kernel<true,true>",
+            "bound": "valu", "achieved": None, "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "Tlane-op/s", "frac": None,
+            "traffic": None,
+            "kernel": dev.trace_kernel_name(),
             "launches_per_step": n_launch, "launch_ms": round(launch_ms, 3),
+            "samples_per_launch": local_samples // max(n_launch, 1),
             "rework_launch_ms": round(float(np.mean(rework_ms)) / max(n_launch, 1), 3) if rework_ms else None,
             "flagged_sample_fraction": round(float(np.mean(flagged)) / max(local_samples, 1), 6) if flagged else None,
             "step_kernels_ms": round(k_ms, 3),
-            "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-            "valu_side_from_committed_pmc": valu,
-            "note": "algorithmic bytes (node/sphere/material records the reference's traversal touches) are served "
-                    "from LDS, not HBM; see DESIGN.md 'Roofline' for the VALU-side reading",
+            "hbm_algorithmic_equiv": {
+                "GBps": round(alg, 1), "over_hbm_peak": round(alg / HBM_PEAK_GBS, 3),
+                "bytes_per_sample": round(bytes_per_sample, 1),
+                "note": "SURVEY.md §8(d) figure: bytes of node/sphere/material records the REFERENCE's walk touches per sample x "
+                        "samples per launch / launch time.  These records are served from LDS and the guarded walk touches "
+                        "fewer of them, so this is NOT comparable with the HBM peak; kept as a secondary figure only."},
+            "committed_profile_valu": committed,
+            "source": "no PMC pass in this process (run `python bench.py` without WORLD_SIZE at N=1 for live counters)",
         }
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -233,5 +439,25 @@ def main():
         dist.destroy_process_group()
 
 
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (invalidates the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="launcher, N = 1: skip the rocprofv3 counter passes")
+    ap.add_argument("--pmc-timeout", type=int, default=240)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: rehearse the N-rank launch + gather over gloo; prints a line without a measurement")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:
+        worker(args)
+        return 0
+    return launcher(args)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

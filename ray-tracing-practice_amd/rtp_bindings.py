@@ -271,6 +271,12 @@ class DeviceScene:
         _check(amd_lib().rt_last_timing(self._h, C.byref(t)), "rt_last_timing")
         return t
 
+    def trace_kernel_name(self):
+        """Name (as rocprofv3 prints it) of the dominant kernel of the most recent rt_render."""
+        t = self.last_timing()
+        lds = "true" if t.scene_in_lds else "false"
+        return f"void rtk::render_kernel<{lds}, {'false' if t.guarded else 'true'}>(rtk::KParams)"
+
     def trace_samples(self, cam, ijs):
         ijs = np.ascontiguousarray(ijs, dtype=np.int32).reshape(-1, 3)
         n = ijs.shape[0]

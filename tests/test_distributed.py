@@ -51,3 +51,31 @@ def test_two_rank_gather_reassembles_frame(tmp_path):
 
 def test_ragged_bands_three_ranks(tmp_path):
     _run(3, 37, 4, tmp_path, 29612)      # 37 rows, bands of 4 over 3 ranks: unequal row counts, partial last band
+
+
+def _bench_dry_run(gpus):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`python bench.py --gpus 2` needs no external launcher: the parent starts two ranks (gloo dry run, no GPU),
+    the collective sees world size 2 and rank 0's line says so."""
+    out = _bench_dry_run(2)
+    assert out["n_gpus"] == 2 and out["world_size_seen_by_collective"] == 2
+    assert out["dry_run"] is True and out["value"] is None and out["assembled_frame_ok"] is True
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
