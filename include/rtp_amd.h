@@ -144,9 +144,46 @@ typedef struct rt_timing {
     uint32_t guarded;         /* 1: guarded near-first walk + exact re-walk of flagged samples; 0: exact walk only */
     uint64_t flagged_samples; /* samples the guarded walk handed to the exact walk (0 when not guarded) */
     float    rework_ms;       /* sum of the exact re-walk launches' durations (0 when not guarded) */
+    uint32_t guard_unproven;  /* 1: the guarded walk ran with rt_config.guard_gamma_ulps below the proven bound */
+    uint32_t kernel;          /* RT_KERNEL_* actually used */
 } rt_timing;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */
+
+/* Library configuration.  The reference has no equivalent (its launch shape is hard-coded,
+ * src/camera.cu:200-204); everything that changes how THIS library renders travels through this struct,
+ * never through the environment.  rt_config_init() fills the defaults; 0 in a field marked "0 = auto"
+ * means the library decides.  Results are the same bits for every setting except where a field says
+ * otherwise. */
+enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_EXACT = 1, RT_TRAVERSAL_GUARDED = 2 };
+enum { RT_BUILD_HOST_SAH = 0, RT_BUILD_DEVICE_LBVH = 1 };
+enum { RT_KERNEL_AUTO = 0, RT_KERNEL_MEGA = 1, RT_KERNEL_WAVEFRONT = 2 };
+typedef struct rt_config {
+    uint32_t struct_bytes;        /* sizeof(rt_config) as the caller compiled it */
+    /* --- fixed at rt_scene_create_ex ------------------------------------------------------------ */
+    int32_t  tree_build;          /* RT_BUILD_*: who builds the guarded walk's own tree */
+    float    guard_gamma_ulps;    /* rounding budget of hit_sphere's discriminant, in units of 2^-24 |oc|^2 |d|^2, that
+                                     the guarded walk's leaf margins cover.  0 = the proven bound (24).  A smaller
+                                     positive value is an UNPROVEN margin: opt-in, reported in rt_timing.guard_unproven */
+    int32_t  guard_exact_leaf_table; /* 1: always upload the exact leaf boxes as a table (developer) */
+    /* --- may be changed between frames with rt_scene_set_config ----------------------------------- */
+    int32_t  traversal;           /* RT_TRAVERSAL_*: AUTO = guarded near-first walk where the scene is eligible and
+                                     has at least guard_min_primitives primitives, else the reference-order walk */
+    int32_t  guard_min_primitives;/* default 16 */
+    int32_t  guard_keep;          /* 1: keep the guarded walk even after a frame that flagged > 2 % of its samples */
+    int32_t  guard_repack;        /* 1 (default): re-pack the guarded tree for a camera outside the reach it was sized for */
+    int32_t  kernel;              /* RT_KERNEL_*: AUTO picks per scene */
+    uint64_t workspace_bytes;     /* budget of the per-pass sample workspace the scene handle owns (0 = default) */
+    int32_t  pass_spp;            /* samples per pixel per pass (0 = auto: what the workspace admits) */
+    int32_t  stack_levels;        /* cap on the guarded walk's per-lane stack entries (0 = auto) */
+    uint32_t flag_capacity;       /* cap on the flagged-sample list (0 = auto; overflow = "re-walk everything") */
+    int32_t  scene_in_lds;        /* 1 (default): stage tables in LDS when they fit; 0: read them through L1/L2 */
+    int32_t  lds_treelet;         /* 1 (default): scenes too big for LDS keep the top of their tree there */
+    int32_t  workgroups_per_cu;   /* 0 = auto */
+    int32_t  k_inner, k_shade;    /* wave scheduling thresholds in lanes (0 = defaults 24 / 48) */
+    int32_t  reserve_chunk;       /* work indices per queue reservation in units of 64 (0 = auto) */
+    int32_t  reserve_taper;       /* 1 (default): reservations shrink towards the end of a pass */
+} rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */
 
@@ -157,6 +194,18 @@ rt_status rt_set_device(int32_t device_ordinal);
  * cudaMemcpyToSymbol(d_scene_data_const) (src/camera.cu:291): validates the arrays, repacks them
  * to the device layout and uploads them once. */
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene);
+
+/* Defaults into *cfg (struct_bytes = sizeof(rt_config)). */
+void rt_config_init(rt_config *cfg);
+/* Developer convenience for test harnesses and tools: overlays the RTP_* environment variables (RTP_TRAVERSAL,
+ * RTP_BUILD, RTP_SLAB_GIB, RTP_PASS_SPP, …; list in INTEGRATION.md) onto *cfg.  The library itself never reads
+ * the environment: a host that wants this behaviour calls it explicitly. */
+void rt_config_from_env(rt_config *cfg);
+/* rt_scene_create with a configuration (NULL = defaults). */
+rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *cfg, rt_scene **out_scene);
+/* Replace the render-time fields of the scene's configuration (the create-time fields are ignored). */
+rt_status rt_scene_set_config(rt_scene *scene, const rt_config *cfg);
+rt_status rt_scene_get_config(const rt_scene *scene, rt_config *cfg);
 
 /* Replaces destroy_scene_arrays / destroy_texture_resources (src/main.cu:235-246,322-344). */
 rt_status rt_scene_destroy(rt_scene *scene);
@@ -176,7 +225,11 @@ int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard);
  * per-sample radiance, added in sample order (src/camera.cu:27-33).  hip_stream is a hipStream_t
  * (NULL = default stream).  With sync != 0 the call waits for the kernel and fills `timing`
  * (may be NULL); with sync == 0 it only enqueues (timing->kernel_ms is then read later with
- * rt_last_kernel_ms()). */
+ * rt_last_kernel_ms()).
+ * Limits: at most 2^24 pixels per call (rt_shard_rows() x image_width; 4K = 2^23) and samples_per_pixel <= 65536 —
+ * RT_ERR_UNSUPPORTED beyond.  The scene must have been created on the calling thread's current device
+ * (RT_ERR_INVALID_ARG otherwise).  One handle renders one frame at a time: calls on the same handle must be
+ * issued to the same stream or separated by a synchronisation. */
 rt_status rt_render(rt_scene *scene, const rt_camera_data *cam, const rt_shard *shard,
                     float *d_fb_sum, void *hip_stream, int32_t sync, rt_timing *timing);
 

@@ -327,18 +327,25 @@ static inline float reflectance(float cosine, float ref_idx) { /* :64-68 */
     return r0 + (1 - r0) * powf((1 - cosine), 5);
 }
 
+/* The uniform-hemisphere scatter.  include/materials.h writes these five lines twice, token for token: as the whole
+ * LAMBERTIAN case (:74-78) and as METAL's 20 % branch (:91-95).  One routine here, so that the reference images
+ * that pin METAL (tests/test_oracle_pins.py) exercise the very code LAMBERTIAN runs — the reference's own scenes
+ * never instantiate LAMBERTIAN. */
+static int scatter_diffuse(const hitrec *rec, v3 *attenuation, ray *scattered, uint32_t *seed, v3 albedo) {
+    v3 dir = random_in_hemisphere(rec->normal, seed);
+    if (near_zero(dir)) dir = rec->normal;
+    scattered->o = rec->point;
+    scattered->d = dir;
+    *attenuation = albedo;
+    return 1;
+}
+
 /* mat->albedo already texture-modulated by the caller (src/camera.cu:268-270). */
 static int material_scatter(const ray *r_in, const hitrec *rec, v3 *attenuation, ray *scattered,
                             uint32_t *seed, const rt_material *mat, v3 albedo) {
     switch (mat->type) {
-        case RT_MAT_LAMBERTIAN: { /* :73-79 */
-            v3 dir = random_in_hemisphere(rec->normal, seed);
-            if (near_zero(dir)) dir = rec->normal;
-            scattered->o = rec->point;
-            scattered->d = dir;
-            *attenuation = albedo;
-            return 1;
-        }
+        case RT_MAT_LAMBERTIAN: /* :73-79 */
+            return scatter_diffuse(rec, attenuation, scattered, seed, albedo);
         case RT_MAT_METAL: { /* :81-96 */
             float p_metal = 0.8f;
             if (orc_random_float(seed) < p_metal) {
@@ -347,14 +354,8 @@ static int material_scatter(const ray *r_in, const hitrec *rec, v3 *attenuation,
                 scattered->d = add(reflected, scale(mat->fuzz, random_in_unit_sphere(seed)));
                 *attenuation = albedo;
                 return dot(scattered->d, rec->normal) > 0;
-            } else {
-                v3 dir = random_in_hemisphere(rec->normal, seed);
-                if (near_zero(dir)) dir = rec->normal;
-                scattered->o = rec->point;
-                scattered->d = dir;
-                *attenuation = albedo;
-                return 1;
             }
+            return scatter_diffuse(rec, attenuation, scattered, seed, albedo);      /* :90-95 */
         }
         case RT_MAT_DIELECTRIC: { /* :98-133 */
             v3 att = V(1.0, 1.0, 1.0);

@@ -202,8 +202,30 @@ uint16_t float_to_half_dir(float f, bool toward_minus_inf) {
     return (uint16_t)((negative ? 0x8000u : 0u) | mag);
 }
 
-std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const float *camera_hint) {
-    out = Packed{};
+namespace {
+
+// pack_scene in steps that share the caller's arrays and the leaves found in them.
+struct Packer {
+    const rt_scene_desc &d;
+    TreeMode mode;
+    Packed &out;
+    PackOptions opt;
+    const float *camera_hint;
+    std::vector<LeafRef> leaves;          // typed leaves of the caller's tree (boxes get inflated by prepare_guard)
+    std::vector<int32_t> depth;           // per caller node
+    std::vector<char> reachable;          // per caller node: reached from the root
+    std::vector<BuildNode> bnodes;        // the traversal tree the pair tables are emitted from
+
+    std::string validate() const;         // counts, indices, textures
+    std::string collect_leaves();         // + the caller's tree is a tree in pre-order
+    void thread_tables();                 // reference-order walk: threaded table and explicit-link table
+    void prepare_guard();                 // guarded walk: eligibility, margins, exact leaf boxes
+    void build_tree();                    // SAH / caller topology / leaves for the device builder
+    void pair_tables();                   // child-pair records (fp32 and binary16), tree depth
+    std::string primitive_tables();       // spheres, planes, materials, textures
+};
+
+std::string Packer::validate() const {
     if (d.num_spheres < 0 || d.num_planes < 0 || d.num_materials < 0 || d.num_nodes < 0 || d.num_textures < 0)
         return "negative element count";
     if ((d.num_spheres && !d.spheres) || (d.num_planes && !d.planes) || (d.num_materials && !d.materials) ||
@@ -225,10 +247,14 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
     for (int i = 0; i < d.num_textures; ++i)
         if (!d.textures[i].rgba || d.textures[i].width <= 0 || d.textures[i].height <= 0) return "bad texture";
 
+    return "";
+}
+
+std::string Packer::collect_leaves() {
     // ---- leaves of the caller's tree, validated to be a tree in pre-order (children after parent)
-    std::vector<LeafRef> leaves;
-    std::vector<int32_t> depth(static_cast<size_t>(d.num_nodes), 0);
-    std::vector<char> reachable(static_cast<size_t>(d.num_nodes), 0);
+    leaves.clear();
+    depth.assign(static_cast<size_t>(d.num_nodes), 0);
+    reachable.assign(static_cast<size_t>(d.num_nodes), 0);
     if (d.num_nodes > 0) reachable[0] = 1;
     for (int k = 0; k < d.num_nodes; ++k) {
         const rt_bvh_node &n = d.nodes[k];
@@ -255,6 +281,10 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
         }
     }
 
+    return "";
+}
+
+void Packer::thread_tables() {
     // ---- threaded copy in the reference's own visit order (iterative DFS, left first)
     {
         struct Item { int32_t node; int32_t stack_ptr; };
@@ -357,15 +387,17 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
         }
     }
 
+}
+
+void Packer::prepare_guard() {
     // ---- guarded mode: eligibility, per-primitive inflation, exact leaf boxes for the final check
     if (mode == TreeMode::Guarded || mode == TreeMode::GuardedLeaves) {
         Packed::Guard &g = out.guard;
         std::string why;
         const double u = 5.9604645e-8;       // 2^-24
-        // error budget of hit_sphere's discriminant, in units of |oc|^2 |d|^2: scenes small enough for LDS get the
-        // term-by-term worst-case bound (it costs them little); big ones, whose margins are already large, a margin
-        // of 16x the largest error observed
-        const double gamma = (int64_t)d.num_spheres + d.num_planes <= kGuardBoundBelow ? double(kGuardGammaBound) : double(kGuardGamma);
+        // error budget of hit_sphere's discriminant, in units of |oc|^2 |d|^2: the term-by-term worst-case bound
+        // (kGuardGammaBound) unless the caller opted into a smaller, unproven margin (rt_config.guard_gamma_ulps)
+        const double gamma = opt.gamma;
         std::vector<int32_t> leaf_of_sphere(static_cast<size_t>(d.num_spheres), -1), leaf_of_plane(static_cast<size_t>(d.num_planes), -1);
         if (leaves.empty()) why = "no primitives";
         else if (d.num_spheres >= (1 << 24) || d.num_planes >= (1 << 24)) why = "too many primitives";
@@ -526,14 +558,17 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
                 for (int a = 0; a < 3; ++a)
                     if (lb[2 * a] != s.center.e[a] - s.radius || lb[2 * a + 1] != s.center.e[a] + s.radius) derivable = false;
             }
-            if (derivable && !getenv("RTP_GUARD_TABLE")) out.leaf_boxes.clear();
+            if (derivable && !opt.leaf_table) out.leaf_boxes.clear();
             g.ok = why.empty();
         }
         g.reason = why;
     }
 
+}
+
+void Packer::build_tree() {
     // ---- traversal tree
-    std::vector<BuildNode> bnodes;
+    bnodes.clear();
     if (mode == TreeMode::GuardedLeaves) {
         // the caller builds the tree itself (device builder, rt_build.hip) from the inflated leaves
         out.root = kTraversalDone;
@@ -603,6 +638,9 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
         out.root = 0;
     }
 
+}
+
+void Packer::pair_tables() {
     // ---- child-pair node table
     // box of a child code: leaf → its exact leaf box; internal → that node's box
     std::vector<const float *> sphere_box(static_cast<size_t>(d.num_spheres), nullptr), plane_box(static_cast<size_t>(d.num_planes), nullptr);
@@ -661,6 +699,9 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
         out.max_depth = maxd;
     }
 
+}
+
+std::string Packer::primitive_tables() {
     // ---- primitive and material tables
     out.spheres.resize(static_cast<size_t>(d.num_spheres) * 4);
     out.sphere_mat.resize(static_cast<size_t>(d.num_spheres));
@@ -702,6 +743,22 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
         texels += n;
     }
     return "";
+}
+
+}  // namespace
+
+std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const PackOptions &opt, const float *camera_hint) {
+    out = Packed{};
+    Packer pk{d, mode, out, opt, camera_hint, {}, {}, {}, {}};
+    std::string err = pk.validate();
+    if (!err.empty()) return err;
+    err = pk.collect_leaves();
+    if (!err.empty()) return err;
+    pk.thread_tables();
+    pk.prepare_guard();
+    pk.build_tree();
+    pk.pair_tables();
+    return pk.primitive_tables();
 }
 
 }  // namespace rtaccel

@@ -78,12 +78,17 @@ struct Packed {
 // guard_leaf_boxes / guard_leaf_codes for a device-side builder (rt_build.h).
 enum class TreeMode { Reference, Sah, Guarded, GuardedLeaves };
 
-// Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2: 16x the largest
-// error observed; the sum of every rounding's worst case would be ~21 x 2^-24.
-constexpr float kGuardGamma = 8.0f * 5.9604645e-8f;
-// … and the bound: scenes of at most kGuardBoundBelow primitives use it.
+// Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2.
+// kGuardGammaBound: the sum of every rounding's worst case is ~21 x 2^-24; 24 is what every scene gets by default.
+// kGuardGammaObserved: 16x the largest error observed in ~10^8 sphere tests — NOT a bound; only used when the caller
+// opts in through rt_config.guard_gamma_ulps (reported as rt_timing.guard_unproven).
 constexpr float kGuardGammaBound = 24.0f * 5.9604645e-8f;
-constexpr int64_t kGuardBoundBelow = 4096;
+constexpr float kGuardGammaObserved = 8.0f * 5.9604645e-8f;
+
+struct PackOptions {
+    double gamma = kGuardGammaBound;   // discriminant error budget the leaf margins cover
+    bool leaf_table = false;           // always emit the exact sphere leaf boxes as a table (developer)
+};
 
 // binary16 helpers of the half-precision node table (exposed for the native test)
 float half_to_float(uint16_t h);
@@ -92,6 +97,7 @@ uint16_t float_to_half_dir(float f, bool toward_minus_inf);
 // Returns "" on success, else a message (→ RT_ERR_INVALID_ARG).
 // camera_hint (3 floats, optional): the guarded walk's margins are sized so that this ray origin is covered
 // too (a camera far outside the scene).
-std::string pack_scene(const rt_scene_desc &desc, TreeMode mode, Packed &out, const float *camera_hint = nullptr);
+std::string pack_scene(const rt_scene_desc &desc, TreeMode mode, Packed &out, const PackOptions &opt = PackOptions(),
+                       const float *camera_hint = nullptr);
 
 }  // namespace rtaccel

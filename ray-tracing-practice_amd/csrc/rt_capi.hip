@@ -14,7 +14,9 @@
 #include "rt_build.h"
 #include "rt_device_math.h"
 #include "rt_kernel.hip.inc"
+#ifdef RTP_DEV_QUEUE_KERNEL      // developer build only (make DEV=1): the slower T-wave/S-wave LDS-queue experiment, DESIGN.md §5b
 #include "rt_kernel_queue.hip.inc"
+#endif
 
 namespace {
 
@@ -33,10 +35,13 @@ rt_status fail(rt_status st, const std::string &msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                              \
     } while (0)
 
+// Only rt_config_from_env() (an explicit call of the host) reads the environment.
 int env_int(const char *name, int fallback) {
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : fallback;
 }
+
+constexpr uint64_t kDefaultWorkspaceBytes = (uint64_t)20 << 30;
 
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr int kMaxPasses = 1024;        // >= 64 samples per pass
@@ -47,27 +52,61 @@ constexpr int kTimedPasses = 64;        // trace launches individually timed per
 constexpr int kQueueWork = 0, kQueueRework = kMaxPasses, kQueueFlag = 2 * kMaxPasses, kQueueStats = 3 * kMaxPasses;
 constexpr int kQueueWords = 3 * kMaxPasses + 16;
 
-// Traversal.  "threaded": the caller's tree in the reference's own visit order — the result is the
-// reference's by construction.  "guarded" (default where the scene is eligible): near-first walk of
-// an SAH tree over inflated leaf boxes; every sample whose result could depend on the visit order
+// Traversal (rt_config.traversal).  EXACT ("threaded"): the caller's tree in the reference's own visit order — the
+// result is the reference's by construction.  GUARDED (AUTO's choice where the scene is eligible): near-first walk
+// of an SAH tree over inflated leaf boxes; every sample whose result could depend on the visit order
 // is flagged and re-walked in threaded mode, so the frame is the same.
-bool threaded_forced() {
-    const char *v = getenv("RTP_TRAVERSAL");
-    return v && std::string(v) == "threaded";
-}
 // Trees of a handful of primitives have nothing to gain from a second walk; everything else eligible gets the
-// guarded one (the reference's default scene, ~200 primitives: 12.4 vs 9.0 Gsamples/s).  RTP_TRAVERSAL=guarded
-// asks for it regardless of size.
-bool guarded_wanted(int64_t primitives) {
-    const char *v = getenv("RTP_TRAVERSAL");
-    if (v && std::string(v) == "guarded") return true;
-    return primitives >= env_int("RTP_GUARD_MIN_PRIMS", 16);
+// guarded one (the reference's default scene, ~200 primitives: 12.4 vs 9.0 Gsamples/s).
+bool guarded_wanted(const rt_config &cfg, int64_t primitives) {
+    if (cfg.traversal == RT_TRAVERSAL_GUARDED) return true;
+    return primitives >= cfg.guard_min_primitives;
+}
+
+void config_defaults(rt_config &c) {
+    std::memset(&c, 0, sizeof(c));
+    c.struct_bytes = (uint32_t)sizeof(rt_config);
+    c.tree_build = RT_BUILD_HOST_SAH;
+    c.guard_gamma_ulps = 0.0f;
+    c.traversal = RT_TRAVERSAL_AUTO;
+    c.guard_min_primitives = 16;
+    c.guard_repack = 1;
+    c.kernel = RT_KERNEL_AUTO;
+    c.workspace_bytes = kDefaultWorkspaceBytes;
+    c.scene_in_lds = 1;
+    c.lds_treelet = 1;
+    c.reserve_taper = 1;
+}
+
+// A caller compiled against an older, shorter rt_config: its fields, defaults for the rest.
+rt_config config_from_caller(const rt_config *in) {
+    rt_config c;
+    config_defaults(c);
+    if (in && in->struct_bytes >= 8) {
+        const size_t n = in->struct_bytes < sizeof(rt_config) ? in->struct_bytes : sizeof(rt_config);
+        std::memcpy(&c, in, n);
+        c.struct_bytes = (uint32_t)sizeof(rt_config);
+    }
+    if (c.workspace_bytes == 0) c.workspace_bytes = kDefaultWorkspaceBytes;
+    if (c.guard_min_primitives < 0) c.guard_min_primitives = 0;
+    return c;
+}
+
+rtaccel::PackOptions pack_options(const rt_config &cfg) {
+    rtaccel::PackOptions o;
+    if (cfg.guard_gamma_ulps > 0.0f) o.gamma = (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8;
+    o.leaf_table = cfg.guard_exact_leaf_table != 0;
+    return o;
+}
+bool gamma_unproven(const rt_config &cfg) {
+    return cfg.guard_gamma_ulps > 0.0f && (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8 < (double)rtaccel::kGuardGammaBound;
 }
 
 }  // namespace
 
 struct rt_scene {
     int device = 0;
+    rt_config cfg{};
     float4 *tnodes = nullptr, *xnodes = nullptr;
     int32_t num_tnodes = 0, num_top = 0, num_top_pairs = 0;
     float4 *hnodes = nullptr;       // pair records with binary16 planes (guarded walk from global memory)
@@ -137,6 +176,17 @@ void normalise_shard(const rt_shard *in, int32_t height, rt_shard &out) {
     }
 }
 
+// A scene's tables live on the device it was created on: calls from a thread whose current device is another one
+// would launch there with this device's pointers.
+rt_status check_device(const rt_scene *sc) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(RT_ERR_HIP, "hipGetDevice failed");
+    if (cur != sc->device)
+        return fail(RT_ERR_INVALID_ARG, "scene was created on device " + std::to_string(sc->device) + " but the calling thread's current device is " +
+                                            std::to_string(cur) + " (call rt_set_device first)");
+    return RT_OK;
+}
+
 rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, rtk::KParams &P) {
     std::memset(&P, 0, sizeof(P));
     if (!sc || !cam) return fail(RT_ERR_INVALID_ARG, "null scene or camera");
@@ -184,8 +234,8 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.g_rs = sc->guard.cluster_radius;
     P.g_fark = sc->guard.far_k;
     std::memcpy(P.g_box, sc->guard.box, 24);
-    P.k_inner = env_int("RTP_K_INNER", 24);
-    P.k_shade = env_int("RTP_K_SHADE", 48);
+    P.k_inner = sc->cfg.k_inner > 0 ? sc->cfg.k_inner : 24;
+    P.k_shade = sc->cfg.k_shade > 0 ? sc->cfg.k_shade : 48;
     P.chunk = 64u;      // set per pass in rt_render
     return RT_OK;
 }
@@ -206,7 +256,7 @@ rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream
     d.planes = planes.data();
     d.materials = &dummy; d.num_materials = 1;
     rtaccel::Packed pk;
-    const std::string err = rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk, cam);
+    const std::string err = rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk, pack_options(sc->cfg), cam);
     if (!err.empty()) return fail(RT_ERR_INVALID_ARG, "re-pack for a far camera: " + err);
     if (!pk.guard.ok) {          // margins for that distance would swallow the tree: such cameras get the exact walk
         sc->repack_refused = true;
@@ -247,18 +297,69 @@ rt_status rt_set_device(int32_t device_ordinal) {
     return RT_OK;
 }
 
-rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
+void rt_config_init(rt_config *cfg) {
+    if (cfg) config_defaults(*cfg);
+}
+
+void rt_config_from_env(rt_config *cfg) {
+    if (!cfg) return;
+    auto str_is = [](const char *name, const char *value) { const char *v = getenv(name); return v && std::string(v) == value; };
+    if (str_is("RTP_TRAVERSAL", "threaded") || str_is("RTP_TRAVERSAL", "exact")) cfg->traversal = RT_TRAVERSAL_EXACT;
+    if (str_is("RTP_TRAVERSAL", "guarded")) cfg->traversal = RT_TRAVERSAL_GUARDED;
+    if (str_is("RTP_BUILD", "device")) cfg->tree_build = RT_BUILD_DEVICE_LBVH;
+    if (str_is("RTP_KERNEL", "mega")) cfg->kernel = RT_KERNEL_MEGA;
+    if (str_is("RTP_KERNEL", "wavefront")) cfg->kernel = RT_KERNEL_WAVEFRONT;
+    if (const char *v = getenv("RTP_GUARD_GAMMA_ULPS")) cfg->guard_gamma_ulps = (float)atof(v);
+    cfg->guard_exact_leaf_table = env_int("RTP_GUARD_TABLE", cfg->guard_exact_leaf_table);
+    cfg->guard_min_primitives = env_int("RTP_GUARD_MIN_PRIMS", cfg->guard_min_primitives);
+    cfg->guard_keep = env_int("RTP_GUARD_KEEP", cfg->guard_keep);
+    if (env_int("RTP_NO_REPACK", 0)) cfg->guard_repack = 0;
+    if (const char *v = getenv("RTP_SLAB_GIB")) { const double g = atof(v); if (g > 0) cfg->workspace_bytes = (uint64_t)(g * 1073741824.0); }
+    cfg->pass_spp = env_int("RTP_PASS_SPP", cfg->pass_spp);
+    cfg->stack_levels = env_int("RTP_STACK_LEVELS", cfg->stack_levels);
+    cfg->flag_capacity = (uint32_t)env_int("RTP_FLAG_CAP", (int)cfg->flag_capacity);
+    if (env_int("RTP_NO_LDS_SCENE", 0)) cfg->scene_in_lds = 0;
+    if (env_int("RTP_NO_TREELET", 0)) cfg->lds_treelet = 0;
+    cfg->workgroups_per_cu = env_int("RTP_WGS_PER_CU", cfg->workgroups_per_cu);
+    cfg->k_inner = env_int("RTP_K_INNER", cfg->k_inner);
+    cfg->k_shade = env_int("RTP_K_SHADE", cfg->k_shade);
+    cfg->reserve_chunk = env_int("RTP_CHUNK", cfg->reserve_chunk);
+    if (env_int("RTP_NO_TAPER", 0)) cfg->reserve_taper = 0;
+}
+
+rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) { return rt_scene_create_ex(desc, nullptr, out_scene); }
+
+rt_status rt_scene_set_config(rt_scene *sc, const rt_config *cfg) {
+    if (!sc || !cfg) return fail(RT_ERR_INVALID_ARG, "null argument");
+    rt_config c = config_from_caller(cfg);
+    // create-time fields keep the values the tables were built with
+    c.tree_build = sc->cfg.tree_build;
+    c.guard_gamma_ulps = sc->cfg.guard_gamma_ulps;
+    c.guard_exact_leaf_table = sc->cfg.guard_exact_leaf_table;
+    sc->cfg = c;
+    return RT_OK;
+}
+
+rt_status rt_scene_get_config(const rt_scene *sc, rt_config *cfg) {
+    if (!sc || !cfg) return fail(RT_ERR_INVALID_ARG, "null argument");
+    *cfg = sc->cfg;
+    return RT_OK;
+}
+
+rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cfg, rt_scene **out_scene) {
     if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARG, "null argument");
     *out_scene = nullptr;
+    const rt_config cfg = config_from_caller(user_cfg);
+    if (cfg.guard_gamma_ulps < 0.0f || !(cfg.guard_gamma_ulps == cfg.guard_gamma_ulps)) return fail(RT_ERR_INVALID_ARG, "guard_gamma_ulps must be >= 0");
     rtaccel::Packed pk;
-    // RTP_BUILD=device: the guarded walk's tree is built on the GPU (LBVH, rt_build.hip) instead of the host's SAH
+    const rtaccel::PackOptions popt = pack_options(cfg);
+    // RT_BUILD_DEVICE_LBVH: the guarded walk's tree is built on the GPU (LBVH, rt_build.hip) instead of the host's SAH
     // builder — any tree over the inflated leaves gives the same image
-    const char *build_env = getenv("RTP_BUILD");
-    const bool device_build = build_env && std::string(build_env) == "device";
-    std::string err = rtaccel::pack_scene(*desc, device_build ? rtaccel::TreeMode::GuardedLeaves : rtaccel::TreeMode::Guarded, pk);
+    const bool device_build = cfg.tree_build == RT_BUILD_DEVICE_LBVH;
+    std::string err = rtaccel::pack_scene(*desc, device_build ? rtaccel::TreeMode::GuardedLeaves : rtaccel::TreeMode::Guarded, pk, popt);
     if (!err.empty()) return fail(RT_ERR_INVALID_ARG, err);
     if (device_build && !pk.guard.ok) {       // not eligible for the guarded walk: nothing to build, exact walk only
-        err = rtaccel::pack_scene(*desc, rtaccel::TreeMode::Guarded, pk);
+        err = rtaccel::pack_scene(*desc, rtaccel::TreeMode::Guarded, pk, popt);
         if (!err.empty()) return fail(RT_ERR_INVALID_ARG, err);
     }
 
@@ -266,6 +367,7 @@ rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
     rt_scene *sc = new (std::nothrow) rt_scene;
     if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    sc->cfg = cfg;
     rt_status st = RT_OK;
     auto bail = [&](rt_status s) { rt_scene_destroy(sc); return s; };
     if (hipGetDevice(&sc->device) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipGetDevice failed"));
@@ -357,7 +459,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     rtk::KParams P;
     rt_status st = fill_params(sc, cam, shard, P);
     if (st != RT_OK) return st;
+    if ((st = check_device(sc)) != RT_OK) return st;
     if (!d_fb_sum) return fail(RT_ERR_INVALID_ARG, "null framebuffer");
+    const rt_config &cfg = sc->cfg;
     hipStream_t stream = (hipStream_t)hip_stream;
     P.fb = d_fb_sum;
     if (timing) std::memset(timing, 0, sizeof(*timing));
@@ -380,13 +484,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     Shape exact{};
     {
         const uint64_t scene_bytes = (((uint64_t)P.num_tnodes + 1) * 2 + prim_f4) * 16;
-        exact.in_lds = !env_int("RTP_NO_LDS_SCENE", 0) && scene_bytes + pool_bytes <= kLdsLimit;
+        exact.in_lds = cfg.scene_in_lds && scene_bytes + pool_bytes <= kLdsLimit;
         // big scene: the top of the tree (explicit-link records [0, num_top)) is staged in LDS
-        exact.num_top = (exact.in_lds || env_int("RTP_NO_TREELET", 0)) ? 0 : P.num_top;
+        exact.num_top = (exact.in_lds || !cfg.lds_treelet) ? 0 : P.num_top;
         const uint64_t per_wg = exact.in_lds ? scene_bytes + pool_bytes : pool_bytes + (uint64_t)exact.num_top * 32u;
         // workgroups per CU: what the register budget admits (RTP_MIN_WAVES waves per SIMD), unless that
         // many LDS-resident scene copies do not fit next to each other
-        exact.wgs_per_cu = env_int("RTP_WGS_PER_CU", 0);
+        exact.wgs_per_cu = cfg.workgroups_per_cu;
         if (exact.wgs_per_cu <= 0) {
             exact.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
             while (exact.wgs_per_cu > 1 && (uint64_t)exact.wgs_per_cu * per_wg > kLdsLimit) --exact.wgs_per_cu;
@@ -396,8 +500,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     }
 
     // ---- guarded near-first walk: only for eligible scenes that fit LDS with a useful stack
-    bool guarded = sc->guard.ok && !threaded_forced() && P.root >= 0 && guarded_wanted((int64_t)P.num_spheres + P.num_planes) &&
-                   !(sc->guard_paused && !env_int("RTP_GUARD_KEEP", 0));
+    bool guarded = sc->guard.ok && cfg.traversal != RT_TRAVERSAL_EXACT && P.root >= 0 && guarded_wanted(cfg, (int64_t)P.num_spheres + P.num_planes) &&
+                   !(sc->guard_paused && !cfg.guard_keep);
     Shape fast{};
     if (guarded) {
         // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
@@ -410,7 +514,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         const bool far_cam = outside(sc->guard.origin_center, (double)sc->guard.origin_radius * sc->guard.origin_radius) ||
                              (sc->guard.num_small > 0 && outside(sc->guard.center, (double)sc->guard.d0_sq));
         if (far_cam && !sc->repack_refused && std::isfinite(cam->origin.e[0]) && std::isfinite(cam->origin.e[1]) &&
-            std::isfinite(cam->origin.e[2]) && !env_int("RTP_NO_REPACK", 0)) {
+            std::isfinite(cam->origin.e[2]) && cfg.guard_repack) {
             st = repack_for_camera(sc, cam->origin.e, stream);
             if (st != RT_OK) return st;
             st = fill_params(sc, cam, shard, P);       // table pointers and guard parameters changed
@@ -434,7 +538,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         };
         const int32_t min_levels = want < 4 ? want : 4;          // a shorter stack flags too many rays
         fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
-        fast.in_lds = !env_int("RTP_NO_LDS_SCENE", 0);
+        fast.in_lds = cfg.scene_in_lds != 0;
         if (fast.in_lds) {
             fast.stack_levels = levels_for(table_bytes, fast.wgs_per_cu);
             while (fast.wgs_per_cu > 1 && fast.stack_levels < min_levels) fast.stack_levels = levels_for(table_bytes, --fast.wgs_per_cu);
@@ -447,19 +551,21 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             fast.stack_levels = levels_for(0, fast.wgs_per_cu);
             if (fast.stack_levels > 12) fast.stack_levels = 12;
         }
-        if (const int forced = env_int("RTP_STACK_LEVELS", 0)) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
+        if (const int forced = cfg.stack_levels) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
         if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
-        if (!fast.in_lds && !env_int("RTP_NO_TREELET", 0)) {
+        if (!fast.in_lds && cfg.lds_treelet) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level;
             const int64_t fit = budget > used ? (int64_t)((budget - used) / 32) : 0;
             fast.num_top = (int32_t)(fit < sc->num_top_pairs ? fit : sc->num_top_pairs);
         }
         fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * 32) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
-        if (const int w = env_int("RTP_WGS_PER_CU", 0)) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
+        if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
     }
     bool use_queue = false;
-    if (const char *kq = getenv("RTP_KERNEL")) use_queue = std::string(kq) == "queue";
+#ifdef RTP_DEV_QUEUE_KERNEL
+    if (const char *kq = getenv("RTP_KERNEL")) use_queue = std::string(kq) == "queue";      // developer build only
+#endif
     if (use_queue) guarded = false;
 
     // Samples per pass: as many as the slab budget admits (default 20 GiB of the 288 GB, RTP_SLAB_GIB),
@@ -469,13 +575,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
     int pass_size = P.spp;
     {
-        const uint64_t budget = (uint64_t)(env_int("RTP_SLAB_GIB", 20) > 0 ? env_int("RTP_SLAB_GIB", 20) : 1) << 30;
+        const uint64_t budget = cfg.workspace_bytes;
         uint64_t fit = budget / ((uint64_t)num_pixels * sizeof(float4));
         const uint64_t index_fit = (((uint64_t)1 << 30) - 64) / num_pixels;     // total_work + 64 <= 2^30
         if (fit > index_fit) fit = index_fit;
         if (fit < 64) fit = 64;
         if ((uint64_t)pass_size > fit) pass_size = (int)fit;
-        if (const int forced = env_int("RTP_PASS_SPP", 0)) pass_size = forced < P.spp ? forced : P.spp;
+        if (const int forced = cfg.pass_spp) pass_size = forced < P.spp ? forced : P.spp;
         rtk::Magic probe;
         while (pass_size > 64 && !make_magic((uint32_t)pass_size, (uint64_t)num_pixels * pass_size + 64, probe)) --pass_size;
     }
@@ -542,8 +648,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         sc->pass_events.push_back(e);
     }
     sc->timed_passes = 0;
-    // RTP_KERNEL=queue: T-waves/S-waves with LDS queues (rt_kernel_queue.hip.inc), exact walk + LDS-resident scenes only
     uint32_t q_lds = 0;
+#ifdef RTP_DEV_QUEUE_KERNEL
+    // RTP_KERNEL=queue: T-waves/S-waves with LDS queues (rt_kernel_queue.hip.inc), exact walk + LDS-resident scenes only
     if (use_queue && exact.in_lds) {
         P.q_s_waves = env_int("RTP_Q_SWAVES", 4);
         P.q_k_refill = env_int("RTP_Q_KREFILL", 16);
@@ -573,6 +680,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if ((uint32_t)wgs > max_wgs) wgs = (int)max_wgs;
         if (wgs < 1) wgs = 1;
     }
+#endif
     for (int pass = 0; pass < passes; ++pass) {
         // samples [pass_first, pass_first + pass_count) of every pixel, traced in any order into the slab …
         const bool timed_pass = pass < kTimedPasses;
@@ -591,25 +699,28 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             const uint64_t waves_total = (uint64_t)wgs * (rtk::kBlock / rtk::kWave);
             uint64_t per = (uint64_t)P.total_work / (waves_total * 16u * 64u);
             per = per < 1 ? 1 : (per > 8 ? 8 : per);
-            if (const int forced = env_int("RTP_CHUNK", 0)) per = (uint64_t)(forced > 0 ? forced : 1);
+            if (const int forced = cfg.reserve_chunk) per = (uint64_t)(forced > 0 ? forced : 1);
             P.chunk = (uint32_t)(64u * per);
             P.taper_shift = 1;                      // remaining / (2 x waves), rounded to a power of two
             while (((uint64_t)1 << P.taper_shift) < 2 * waves_total) ++P.taper_shift;
-            if (env_int("RTP_NO_TAPER", 0)) P.taper_shift = 0;
+            if (!cfg.reserve_taper) P.taper_shift = 0;
         }
+#ifdef RTP_DEV_QUEUE_KERNEL
         if (use_queue) {
             P.stack_levels = 0;
             HIP_TRY(hipFuncSetAttribute((const void *)rtk::render_kernel_q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds));
             hipLaunchKernelGGL(rtk::render_kernel_q<true>, dim3(wgs), dim3(rtk::kQBlock), q_lds, stream, P);
             HIP_TRY(hipGetLastError());
-        } else if (guarded) {
+        } else
+#endif
+        if (guarded) {
             // near-first walk; samples it cannot vouch for go to the list …
             P.stack_levels = fast.stack_levels;
             P.num_top = fast.num_top;
             P.flag_list = sc->flag_list;
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
-            if (const int tiny = env_int("RTP_FLAG_CAP", 0)) P.flag_cap = (uint32_t)tiny < P.flag_cap ? (uint32_t)tiny : P.flag_cap;   // test hook: overflow path
+            if (const uint32_t tiny = cfg.flag_capacity) P.flag_cap = tiny < P.flag_cap ? tiny : P.flag_cap;   // test hook: overflow path
             if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
             else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
             if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
@@ -639,11 +750,17 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->timed = true;
     sc->last = rt_timing{};
     sc->last.num_workgroups = (uint32_t)wgs;
-    sc->last.workgroup_size = use_queue ? rtk::kQBlock : rtk::kBlock;
-    sc->last.lds_bytes = use_queue ? q_lds : main_shape.lds_bytes;
+    sc->last.workgroup_size = rtk::kBlock;
+    sc->last.lds_bytes = main_shape.lds_bytes;
+#ifdef RTP_DEV_QUEUE_KERNEL
+    if (use_queue) { sc->last.workgroup_size = rtk::kQBlock; sc->last.lds_bytes = q_lds; }
+#endif
+    (void)q_lds;
     sc->last.scene_in_lds = main_shape.in_lds ? 1u : 0u;
     sc->last.trace_launches = (uint32_t)passes;
     sc->last.guarded = guarded ? 1u : 0u;
+    sc->last.guard_unproven = (guarded && gamma_unproven(cfg)) ? 1u : 0u;
+    sc->last.kernel = RT_KERNEL_MEGA;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);
@@ -725,6 +842,7 @@ rt_status rt_trace_samples(rt_scene *sc, const rt_camera_data *cam, int32_t n, c
     rtk::KParams P;
     rt_status st = fill_params(sc, cam, nullptr, P);
     if (st != RT_OK) return st;
+    if ((st = check_device(sc)) != RT_OK) return st;
     if (n == 0) return RT_OK;
     for (int32_t k = 0; k < n; ++k)
         if (ijs[3 * k] < 0 || ijs[3 * k] >= cam->image_width || ijs[3 * k + 1] < 0 || ijs[3 * k + 1] >= cam->image_height || ijs[3 * k + 2] < 0)
@@ -760,6 +878,7 @@ rt_status rt_closest_hits(rt_scene *sc, int32_t n, const float *origins, const f
     rtk::KParams P;
     rt_status st = fill_params(sc, &cam, nullptr, P);
     if (st != RT_OK) return st;
+    if ((st = check_device(sc)) != RT_OK) return st;
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     int32_t *d_hit = nullptr, *d_prim = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_hit); (void)hipFree(d_prim); };

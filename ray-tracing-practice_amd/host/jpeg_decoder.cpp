@@ -1,17 +1,24 @@
 // jpeg_decoder.cpp — baseline (sequential, Huffman, 8-bit) JPEG decoder for the host texture loader.
 //
-// The reference decodes its floor texture with the vendored third-party stb_image
-// (stbi_loadf(path, &w, &h, &c, 4), src/main.cu:52-60), which is not part of this repository.  A
-// texture decoded by a DIFFERENT JPEG decoder (different IDCT rounding or chroma upsampling) gives
-// different texels and therefore a different image, so this decoder follows the published
-// integer pipeline of that decoder family step for step — 12-bit fixed-point "islow"-style IDCT
-// applied to coefficients dequantised at entropy-decode time, triangle ("fancy") 2x chroma
-// upsampling, 20-bit fixed-point YCbCr→RGB — and tests/test_oracle_pins.py checks it byte for byte
-// against the reference's own decoder on the reference's floor.jpg (build container only).
+// PROVENANCE.  This file is a restatement of the JPEG path of stb_image v2.30 (Sean Barrett et al.; public domain /
+// MIT, dual-licensed — https://github.com/nothings/stb), the decoder the reference vendors as include/stb_image.h and
+// calls as stbi_loadf(path, &w, &h, &c, 4) (src/main.cu:52-60).  It is NOT an independent design: a texture decoded by
+// a different JPEG decoder (other IDCT rounding, other chroma upsampling) gives different texels and therefore a
+// different image than the reference's, so the arithmetic follows stb_image's step for step and several tables and
+// idioms are stb_image's own: the de-zigzag table with its 15 padding entries, the maxcode/delta canonical-Huffman
+// layout with a 9-bit fast table, the bit-buffer refill ("grow") and the rotate-based extend-receive, the 12-bit
+// fixed-point "islow"-style IDCT applied to coefficients dequantised at entropy-decode time (its constants and
+// temporaries), the triangle ("fancy") h2/v2/hv2 chroma upsamplers with their div4/div16 rounding, and the 20-bit
+// fixed-point YCbCr→RGB with the `& 0xffff0000` step.  SURVEY.md lists stb itself as third-party and out of scope;
+// what is restated here is only the baseline path the reference's floor.jpg needs, reorganised around std::vector
+// and a Decoder struct.  tests/test_oracle_pins.py checks it texel for texel against the reference's own vendored
+// stb_image.h on the reference's floor.jpg (build container only).
 //
 // Supported: SOF0/SOF1 (baseline / extended sequential, 8-bit), 1 or 3 components, sampling
 // factors 1 or 2, restart intervals.  Progressive, arithmetic-coded, 12-bit and CMYK files are
 // rejected (load fails like a failed stbi_loadf: the material stays untextured).
+// Unlike stb_image, images larger than kMaxTextureDim per side or kMaxTexturePixels in all are rejected before
+// anything is allocated (a 65535 x 65535 header would otherwise ask for 12.9 GB of RGB plus 68 GB of float RGBA).
 #include "jpeg_decoder.h"
 
 #include <cstdint>
@@ -21,6 +28,9 @@
 
 namespace rtp {
 namespace {
+
+constexpr int kMaxTextureDim = 16384;
+constexpr int64_t kMaxTexturePixels = int64_t(1) << 26;      // 64 Mpixel = 1 GiB of float RGBA on the device
 
 const uint8_t kDezigzag[64 + 15] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
                                     6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
@@ -303,6 +313,7 @@ struct Decoder {
         img_y = get16();
         img_x = get16();
         if (img_x <= 0 || img_y <= 0) return false;
+        if (img_x > kMaxTextureDim || img_y > kMaxTextureDim || static_cast<int64_t>(img_x) * img_y > kMaxTexturePixels) return false;
         img_n = get8();
         if (img_n != 3 && img_n != 1) return false;
         if (Lf != 8 + 3 * img_n) return false;

@@ -42,14 +42,43 @@ void Camera::render(float *d_fb) const {
 }
 
 
+// Frame file name.  The reference hands the pattern it read from the config straight to
+// snprintf(filename, 256, pattern, n) (src/camera.cu:298-299): a pattern with anything but one integer conversion
+// is undefined behaviour there.  Same result for the patterns that are defined — "%d", "%5d", "%03d", "%%", the
+// 255-character truncation — and a clean failure (message + exit 99, like every other fatal error of the driver)
+// for the rest, instead of passing untrusted text to printf.
+std::string frame_filename(const std::string &pattern, int n) {
+    std::string out;
+    int conversions = 0;
+    for (size_t k = 0; k < pattern.size(); ++k) {
+        if (pattern[k] != '%') { out.push_back(pattern[k]); continue; }
+        if (k + 1 < pattern.size() && pattern[k + 1] == '%') { out.push_back('%'); ++k; continue; }
+        size_t e = k + 1;
+        std::string spec = "%";
+        if (e < pattern.size() && (pattern[e] == '0' || pattern[e] == '-')) spec.push_back(pattern[e++]);
+        int digits = 0;
+        while (e < pattern.size() && pattern[e] >= '0' && pattern[e] <= '9' && digits < 3) { spec.push_back(pattern[e++]); ++digits; }
+        if (e >= pattern.size() || (pattern[e] != 'd' && pattern[e] != 'i') || ++conversions > 1) {
+            std::fprintf(stderr, "output path pattern '%s': only one %%d (optionally %%0Nd / %%Nd) is supported\n", pattern.c_str());
+            std::exit(99);
+        }
+        spec.push_back('d');
+        char buf[32];
+        std::snprintf(buf, sizeof(buf), spec.c_str(), n);
+        out += buf;
+        k = e;
+    }
+    if (out.size() > 255) out.resize(255);
+    return out;
+}
+
 void gpu_render(const SceneParams &params) {
     float *d_fb = nullptr;
     const size_t num_pixels = static_cast<size_t>(params.width) * params.height;
     RTP_CHECK(rt_device_alloc(num_pixels * 3 * sizeof(float), reinterpret_cast<void **>(&d_fb)));
 
     for (int n = 0; n < params.num_frames; ++n) {
-        char filename[256];
-        snprintf(filename, sizeof(filename), params.output_pattern.c_str(), n);
+        const std::string filename = frame_filename(params.output_pattern, n);
         auto saver = std::make_unique<BinarySaver>(params.sqrt_spp, filename);
         Vec3 eye, target;
         orbit_pose(params, n, eye, target);
@@ -111,8 +140,7 @@ void gpu_render_pipelined(const SceneParams &params, const rt_scene_desc &desc, 
         RTP_CHECK(rt_device_alloc(num_pixels * 3, reinterpret_cast<void **>(&d_rgb)));
         std::thread writer;
         for (int n = dev; n < params.num_frames; n += num_devices) {
-            char filename[256];
-            snprintf(filename, sizeof(filename), params.output_pattern.c_str(), n);
+            const std::string filename = frame_filename(params.output_pattern, n);
             Vec3 eye, target;
             orbit_pose(params, n, eye, target);
             Camera camera(params.height, params.width, nullptr, eye, target);

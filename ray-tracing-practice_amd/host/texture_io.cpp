@@ -60,7 +60,8 @@ bool load_texture(const std::string &path, TextureImage &out) {
     }
     in.get();  // single whitespace after the header
     const int w = atoi(tw.c_str()), h = atoi(th.c_str());
-    if (w <= 0 || h <= 0) {
+    // same caps as the JPEG path: a hostile header must not size a multi-gigabyte allocation
+    if (w <= 0 || h <= 0 || w > 16384 || h > 16384 || static_cast<long long>(w) * h > (1ll << 26)) {
         std::cerr << "Failed to load texture: " << path << std::endl;
         return false;
     }

@@ -61,7 +61,23 @@ class Shard(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("num_workgroups", C.c_uint32), ("workgroup_size", C.c_uint32),
                 ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("trace_launches", C.c_uint32),
-                ("trace_ms", C.c_float), ("guarded", C.c_uint32), ("flagged_samples", C.c_uint64), ("rework_ms", C.c_float)]
+                ("trace_ms", C.c_float), ("guarded", C.c_uint32), ("flagged_samples", C.c_uint64), ("rework_ms", C.c_float),
+                ("guard_unproven", C.c_uint32), ("kernel", C.c_uint32)]
+
+
+TRAVERSAL_AUTO, TRAVERSAL_EXACT, TRAVERSAL_GUARDED = 0, 1, 2
+BUILD_HOST_SAH, BUILD_DEVICE_LBVH = 0, 1
+KERNEL_AUTO, KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1, 2
+
+
+class Config(C.Structure):
+    """rt_config (include/rtp_amd.h)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("tree_build", C.c_int32), ("guard_gamma_ulps", C.c_float),
+                ("guard_exact_leaf_table", C.c_int32), ("traversal", C.c_int32), ("guard_min_primitives", C.c_int32),
+                ("guard_keep", C.c_int32), ("guard_repack", C.c_int32), ("kernel", C.c_int32), ("workspace_bytes", C.c_uint64),
+                ("pass_spp", C.c_int32), ("stack_levels", C.c_int32), ("flag_capacity", C.c_uint32), ("scene_in_lds", C.c_int32),
+                ("lds_treelet", C.c_int32), ("workgroups_per_cu", C.c_int32), ("k_inner", C.c_int32), ("k_shade", C.c_int32),
+                ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32)]
 
 
 class ConfigInfo(C.Structure):
@@ -74,7 +90,8 @@ assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
 
 # Every symbol include/rtp_amd.h declares (tests check that the library exports all of them).
 RTP_AMD_SYMBOLS = [
-    "rt_set_device", "rt_scene_create", "rt_scene_destroy", "rt_scene_guard_reason", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
+    "rt_set_device", "rt_scene_create", "rt_scene_create_ex", "rt_config_init", "rt_config_from_env", "rt_scene_set_config",
+    "rt_scene_get_config", "rt_scene_destroy", "rt_scene_guard_reason", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
     "rt_last_timing",
     "rt_render_to_host", "rt_trace_samples", "rt_closest_hits", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
     "rt_get_last_error_string", "rt_version_string",
@@ -124,6 +141,13 @@ def amd_lib():
         lib.rt_set_device.argtypes = [C.c_int32]
         lib.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         lib.rt_scene_destroy.argtypes = [C.c_void_p]
+        lib.rt_config_init.argtypes = [C.POINTER(Config)]
+        lib.rt_config_init.restype = None
+        lib.rt_config_from_env.argtypes = [C.POINTER(Config)]
+        lib.rt_config_from_env.restype = None
+        lib.rt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
+        lib.rt_scene_set_config.argtypes = [C.c_void_p, C.POINTER(Config)]
+        lib.rt_scene_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
         lib.rt_scene_guard_reason.argtypes = [C.c_void_p]
         lib.rt_scene_guard_reason.restype = C.c_char_p
         lib.rt_shard_rows.argtypes = [C.c_int32, C.POINTER(Shard)]
@@ -234,21 +258,55 @@ def binary_image_bytes(fb_sum, width, height, divisor):
 
 
 class DeviceScene:
-    """rt_scene handle (device-resident repacked scene)."""
+    """rt_scene handle (device-resident repacked scene).
 
-    def __init__(self, host_scene, device=None):
+    Configuration: keyword arguments are rt_config fields (e.g. traversal=rb.TRAVERSAL_EXACT, pass_spp=64,
+    tree_build=rb.BUILD_DEVICE_LBVH); configure(**fields) changes the render-time ones later.  With
+    honour_env=True (the default of this TEST/TOOL binding, not of the library, which never reads the
+    environment) the RTP_* developer variables are overlaid through rt_config_from_env() at creation and
+    before every render, so a harness can flip a knob around a single call."""
+
+    def __init__(self, host_scene, device=None, honour_env=True, **config):
         lib = amd_lib()
         if device is not None:
             _check(lib.rt_set_device(device), "rt_set_device")
         self._h = C.c_void_p()
-        _check(lib.rt_scene_create(C.byref(host_scene.desc), C.byref(self._h)), "rt_scene_create")
+        self._honour_env = honour_env
+        self._explicit = dict(config)
+        cfg = self._make_config()
+        _check(lib.rt_scene_create_ex(C.byref(host_scene.desc), C.byref(cfg), C.byref(self._h)), "rt_scene_create_ex")
         self._keep = host_scene
+
+    def _make_config(self):
+        cfg = Config()
+        amd_lib().rt_config_init(C.byref(cfg))
+        assert cfg.struct_bytes == C.sizeof(Config), (cfg.struct_bytes, C.sizeof(Config))
+        for k, v in self._explicit.items():
+            setattr(cfg, k, v)
+        if self._honour_env:
+            amd_lib().rt_config_from_env(C.byref(cfg))
+        return cfg
+
+    def configure(self, **fields):
+        """Change render-time rt_config fields of this handle."""
+        self._explicit.update(fields)
+        self._apply_config()
+
+    def _apply_config(self):
+        cfg = self._make_config()
+        _check(amd_lib().rt_scene_set_config(self._h, C.byref(cfg)), "rt_scene_set_config")
+
+    def config(self):
+        cfg = Config()
+        _check(amd_lib().rt_scene_get_config(self._h, C.byref(cfg)), "rt_scene_get_config")
+        return cfg
 
     def render_to_host(self, cam, shard=None):
         lib = amd_lib()
         rows = lib.rt_shard_rows(cam.image_height, C.byref(shard) if shard else None)
         fb = np.empty((rows, cam.image_width, 3), dtype=np.float32)
         t = Timing()
+        self._apply_config()
         _check(lib.rt_render_to_host(self._h, C.byref(cam), C.byref(shard) if shard else None, fb.ctypes.data,
                                      C.byref(t)), "rt_render_to_host")
         return fb, t
@@ -256,6 +314,7 @@ class DeviceScene:
     def render(self, cam, d_fb_ptr, shard=None, stream=None, sync=True):
         """d_fb_ptr: integer device address (e.g. torch tensor.data_ptr())."""
         t = Timing()
+        self._apply_config()
         _check(amd_lib().rt_render(self._h, C.byref(cam), C.byref(shard) if shard else None, C.c_void_p(d_fb_ptr),
                                    C.c_void_p(stream or 0), 1 if sync else 0, C.byref(t)), "rt_render")
         return t

@@ -40,6 +40,27 @@ long sweep_identities(unsigned stride) {
     }
     return bad;
 }
+// ELLIPSE interior test: the reference writes powf(x, 2) with a literal exponent (include/plane.h:41); the kernel
+// evaluates x * x.  `literal`: the call as the reference writes it, which gcc/clang/nvcc at -O1 and above expand to
+// x * x (both of the reference's build files use -O3; the oracle is built with -O2); `libm`: the library routine
+// itself, reached through a volatile pointer — what an unoptimised build would call.
+// Inputs: (a) every x whose exact square is a TIE between two floats (x = k * 2^e, k odd, 2^24 < k^2 < 2^25);
+// (b) a strided sweep of [2^-30, 8) and its negatives.
+static float (*volatile libm_powf)(float, float) = powf;
+long sweep_square(unsigned stride, int use_libm, long *total) {
+    long bad = 0, n = 0;
+    for (int k = 4097; k <= 5791; k += 2)
+        for (int e = -40; e <= 20; ++e)
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                const float x = ldexpf((float)(sgn ? -k : k), e);
+                const float p1 = use_libm ? libm_powf(x, 2) : powf(x, 2), p2 = x * x; if (memcmp(&p1, &p2, 4)) bad++; n++;
+            }
+    for (unsigned long u = 0x30800000ul; u < 0x41000000ul; u += stride) { unsigned b = (unsigned)u; float x; memcpy(&x, &b, 4);
+        const float p2 = x * x;
+        float p1 = use_libm ? libm_powf(x, 2) : powf(x, 2); if (memcmp(&p1, &p2, 4)) bad++;
+        p1 = use_libm ? libm_powf(-x, 2) : powf(-x, 2); if (memcmp(&p1, &p2, 4)) bad++; n += 2; }
+    *total = n; return bad;
+}
 unsigned dm_wang(unsigned s) { return rtd::wang_hash(s); }
 float dm_rand(unsigned *s) { return rtd::random_float(*s); }
 unsigned char dm_tonemap(float sum, float inv) { return rtd::tonemap_u8(sum, inv); }
@@ -61,6 +82,8 @@ def dm(tmp_path_factory):
     lib.sweep_pow5.argtypes = [C.c_uint, C.POINTER(C.c_long)]
     lib.sweep_identities.restype = C.c_long
     lib.sweep_identities.argtypes = [C.c_uint]
+    lib.sweep_square.restype = C.c_long
+    lib.sweep_square.argtypes = [C.c_uint, C.c_int, C.POINTER(C.c_long)]
     lib.dm_wang.restype = C.c_uint
     lib.dm_rand.restype = C.c_float
     lib.dm_rand.argtypes = [C.POINTER(C.c_uint)]
@@ -85,6 +108,20 @@ def test_pow5_is_within_libm_noise(dm):
 
 def test_single_op_through_double_equals_float_op(dm):
     assert dm.sweep_identities(1009) == 0
+
+
+def test_square_is_what_an_optimised_build_makes_of_powf_2(dm):
+    """ELLIPSE interior test (include/plane.h:41: powf(x, 2); rt_kernel.hip.inc: x * x).  With the literal exponent
+    every optimising compiler expands the call to x * x — checked here on the code gcc makes of it with the oracle's
+    flags (-O2, no fast-math): identical on all 103 k exact-tie inputs and on every 5th float of [2^-30, 8) and the
+    negatives (111 M values).  That is the parity target: both of the reference's build files compile with -O3.
+    The library routine itself (what an UNoptimised build calls) is not correctly rounded: glibc 2.35's powf(x, 2)
+    differs from x * x by one ulp on ~0.07 % of the sweep and on most exact ties — measured, not asserted to be zero;
+    the bound below only keeps the documented figure honest."""
+    total = C.c_long()
+    assert dm.sweep_square(5, 0, C.byref(total)) == 0 and total.value > 100_000_000
+    bad = dm.sweep_square(5, 1, C.byref(total))
+    assert bad / total.value < 2e-3
 
 
 def test_rng_and_tonemap_match_oracle(dm, golden):

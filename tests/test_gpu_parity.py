@@ -340,26 +340,41 @@ def test_cli_frame_drivers_write_reference_bytes(test_config_text, golden, tmp_p
 
 
 def test_alternative_kernels_agree_with_default(rtiow):
-    """The exact walk alone (RTP_TRAVERSAL=threaded) and the experimental T/S-wave kernel
-    (RTP_KERNEL=queue) must give the bits of the default (guarded walk + exact re-walk)."""
+    """The exact walk alone (rt_config.traversal = RT_TRAVERSAL_EXACT) must give the bits of the default
+    (guarded walk + exact re-walk).  Set through the configuration API, not the environment."""
     host, dev = rtiow
     cam = rb.rtiow_camera(320, 200, 8, 50)
     want, t = dev.render_to_host(cam)
-    assert t.guarded == 1
+    assert t.guarded == 1 and t.guard_unproven == 0
     assert_same_frame(want, ob.render(host, cam, threads=8), "default kernel")
     try:
-        os.environ["RTP_KERNEL"] = "queue"
-        got, t = dev.render_to_host(cam)
-        assert t.workgroup_size == 1024 and t.guarded == 0
-        assert_same_frame(got, want, "queue kernel")
-        del os.environ["RTP_KERNEL"]
-        os.environ["RTP_TRAVERSAL"] = "threaded"
+        dev.configure(traversal=rb.TRAVERSAL_EXACT)
+        assert dev.config().traversal == rb.TRAVERSAL_EXACT
         got, t = dev.render_to_host(cam)
         assert t.guarded == 0 and t.flagged_samples == 0
         assert_same_frame(got, want, "exact walk only")
     finally:
-        os.environ.pop("RTP_KERNEL", None)
-        os.environ.pop("RTP_TRAVERSAL", None)
+        dev.configure(traversal=rb.TRAVERSAL_AUTO)
+
+
+def test_config_api_without_environment():
+    """A handle created with honour_env=False takes everything from rt_config: forced pass size, a capped stack,
+    an opt-in unproven margin (reported in rt_timing.guard_unproven) — frames are the oracle's in every case."""
+    host = rb.HostScene.rtiow()
+    cam = rb.rtiow_camera(160, 90, 70, 50)
+    want = ob.render(host, cam, threads=8)
+    dev = rb.DeviceScene(host, device=0, honour_env=False, pass_spp=64, stack_levels=3)
+    fb, t = dev.render_to_host(cam)
+    assert t.trace_launches == 2 and t.guarded == 1 and t.guard_unproven == 0
+    assert_same_frame(fb, want, "pass_spp=64, stack_levels=3")
+    dev2 = rb.DeviceScene(host, device=0, honour_env=False, guard_gamma_ulps=8.0)
+    fb, t = dev2.render_to_host(cam)
+    assert t.guarded == 1 and t.guard_unproven == 1
+    assert_same_frame(fb, want, "guard_gamma_ulps=8 (opt-in, unproven)")
+    dev3 = rb.DeviceScene(host, device=0, honour_env=False, workspace_bytes=160 * 90 * 16 * 64)
+    fb, t = dev3.render_to_host(cam)
+    assert t.trace_launches == 2
+    assert_same_frame(fb, want, "workspace for 64 spp per pass")
 
 
 def test_guarded_walk_flags_and_rewalks(rtiow, force_guarded):

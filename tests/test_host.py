@@ -140,3 +140,56 @@ def test_product_does_not_reference_the_oracle():
                 continue
             text = open(os.path.join(dirpath, f), errors="ignore").read()
             assert "rt_oracle" not in text and "oracle_bindings" not in text and "librt_oracle" not in text, f
+
+
+def test_lambertian_and_metal_diffuse_share_one_routine():
+    """include/materials.h spells the uniform-hemisphere scatter twice (LAMBERTIAN :74-78, METAL's 20 % branch
+    :91-95).  The reference's own scenes never instantiate LAMBERTIAN, so the reference images (sha256 pins) only
+    run the METAL copy.  Kernel and oracle each have ONE routine that both materials reach, so those pins cover
+    LAMBERTIAN's arithmetic by construction: one definition, one call site in shade() / two calls of the same
+    routine in the oracle, and no second copy of the hemisphere flip anywhere."""
+    import re
+    k = open(os.path.join(ROOT, "ray-tracing-practice_amd", "csrc", "rt_kernel.hip.inc")).read()
+    code = "\n".join(line.split("//")[0] for line in k.splitlines())
+    assert len(re.findall(r"\bf3 scatter_diffuse_dir\(", code)) == 1
+    assert len(re.findall(r"=\s*scatter_diffuse_dir\(", code)) == 1
+    shade = code[code.index("bool shade("):code.index("void start_sample(")]
+    assert "scatter_diffuse_dir(in_sphere, normal)" in shade
+    # the one draw that feeds it is shared by both materials, and nothing else flips a vector into the hemisphere
+    assert "if (is_lamb || is_metal) in_sphere = random_in_unit_sphere(L.seed);" in shade
+    assert len(re.findall(r"dot\(u, normal\) > 0\.0f \? u : neg\(u\)", code)) == 1
+    o = open(os.path.join(ROOT, "oracle", "rt_oracle.c")).read()
+    assert len(re.findall(r"static int scatter_diffuse\(", o)) == 1
+    assert len(re.findall(r"return scatter_diffuse\(rec, attenuation, scattered, seed, albedo\);", o)) == 2
+    assert len(re.findall(r"random_in_hemisphere\(rec->normal, seed\)", o)) == 1
+
+
+def test_config_defaults_and_env_overlay():
+    """rt_config: defaults, forward compatibility of struct_bytes, and the explicit environment overlay (the library
+    itself never reads the environment — only rt_config_from_env does)."""
+    lib = rb.amd_lib()
+    cfg = rb.Config()
+    lib.rt_config_init(C.byref(cfg))
+    assert cfg.struct_bytes == C.sizeof(rb.Config)
+    assert cfg.traversal == rb.TRAVERSAL_AUTO and cfg.guard_gamma_ulps == 0.0 and cfg.guard_min_primitives == 16
+    assert cfg.guard_repack == 1 and cfg.scene_in_lds == 1 and cfg.lds_treelet == 1 and cfg.reserve_taper == 1
+    assert cfg.workspace_bytes > 0
+    saved = {k: os.environ.get(k) for k in ("RTP_TRAVERSAL", "RTP_PASS_SPP", "RTP_GUARD_GAMMA_ULPS", "RTP_SLAB_GIB")}
+    try:
+        os.environ.update(RTP_TRAVERSAL="threaded", RTP_PASS_SPP="64", RTP_GUARD_GAMMA_ULPS="8", RTP_SLAB_GIB="2")
+        lib.rt_config_from_env(C.byref(cfg))
+        assert cfg.traversal == rb.TRAVERSAL_EXACT and cfg.pass_spp == 64 and cfg.guard_gamma_ulps == 8.0
+        assert cfg.workspace_bytes == 2 << 30
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    src = open(os.path.join(ROOT, "ray-tracing-practice_amd", "csrc", "rt_capi.hip")).read()
+    render = src[src.index("rt_status rt_render(rt_scene *sc"):src.index("rt_status rt_last_timing(")]
+    shipped = re_strip_dev(render)
+    assert "getenv" not in shipped and "env_int" not in shipped
+
+
+def re_strip_dev(text):
+    """Drop the #ifdef RTP_DEV_QUEUE_KERNEL … #endif blocks (developer build only)."""
+    import re
+    return re.sub(r"#ifdef RTP_DEV_QUEUE_KERNEL.*?#endif", "", text, flags=re.S)
