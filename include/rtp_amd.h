@@ -183,6 +183,8 @@ typedef struct rt_config {
     int32_t  k_inner, k_shade;    /* wave scheduling thresholds in lanes (0 = defaults 24 / 48) */
     int32_t  reserve_chunk;       /* work indices per queue reservation in units of 64 (0 = auto) */
     int32_t  reserve_taper;       /* 1 (default): reservations shrink towards the end of a pass */
+    int32_t  wavefront_paths;     /* RT_KERNEL_WAVEFRONT: paths in flight per wave, >= 128 (0 = auto) */
+    int32_t  wavefront_exchange;  /* … lanes that must be free before a wave exchanges results for new rays (0 = auto) */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */

@@ -14,6 +14,7 @@
 #include "rt_build.h"
 #include "rt_device_math.h"
 #include "rt_kernel.hip.inc"
+#include "rt_kernel_wf.hip.inc"
 #ifdef RTP_DEV_QUEUE_KERNEL      // developer build only (make DEV=1): the slower T-wave/S-wave LDS-queue experiment, DESIGN.md §5b
 #include "rt_kernel_queue.hip.inc"
 #endif
@@ -41,7 +42,8 @@ int env_int(const char *name, int fallback) {
     return (v && *v) ? atoi(v) : fallback;
 }
 
-constexpr uint64_t kDefaultWorkspaceBytes = (uint64_t)20 << 30;
+constexpr uint64_t kDefaultWorkspaceBytes = ((uint64_t)4 << 30) - ((uint64_t)64 << 20);      // just under 4 GiB
+constexpr uint64_t kSampleBytes = 12;        // one radiance record of the slab
 
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr int kMaxPasses = 1024;        // >= 64 samples per pass
@@ -114,8 +116,8 @@ struct rt_scene {
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
     uint32_t *queue = nullptr;      // counter block, see kQueue*
-    float4 *slab = nullptr;         // per-sample radiance workspace of one pass, grown on demand
-    size_t slab_float4s = 0;
+    float *slab = nullptr;          // per-sample radiance workspace of one pass (3 floats per sample), grown on demand
+    size_t slab_floats = 0;
     rtaccel::Packed::Guard guard;   // guarded-walk eligibility and parameters
     // host copies of what the guard depends on: a camera outside the reach the margins were sized for makes
     // rt_render re-pack the guarded walk's tree for it (reach only ever grows)
@@ -129,6 +131,8 @@ struct rt_scene {
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
+    float4 *wf_pool = nullptr;      // render_kernel_wf: ray/hit stacks of every resident wave, grown on demand
+    size_t wf_pool_float4s = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> pass_events;   // per pass: before the trace launch, after it, after the exact re-walk (first kTimedPasses passes)
@@ -324,6 +328,8 @@ void rt_config_from_env(rt_config *cfg) {
     cfg->k_inner = env_int("RTP_K_INNER", cfg->k_inner);
     cfg->k_shade = env_int("RTP_K_SHADE", cfg->k_shade);
     cfg->reserve_chunk = env_int("RTP_CHUNK", cfg->reserve_chunk);
+    cfg->wavefront_paths = env_int("RTP_WF_PATHS", cfg->wavefront_paths);
+    cfg->wavefront_exchange = env_int("RTP_WF_EXCHANGE", cfg->wavefront_exchange);
     if (env_int("RTP_NO_TAPER", 0)) cfg->reserve_taper = 0;
 }
 
@@ -428,7 +434,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->xnodes);
     (void)hipFree(sc->nodes); (void)hipFree(sc->hnodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
-    (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list);
+    (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list); (void)hipFree(sc->wf_pool);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
@@ -503,6 +509,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     bool guarded = sc->guard.ok && cfg.traversal != RT_TRAVERSAL_EXACT && P.root >= 0 && guarded_wanted(cfg, (int64_t)P.num_spheres + P.num_planes) &&
                    !(sc->guard_paused && !cfg.guard_keep);
     Shape fast{};
+    // kernel form of the guarded pass: render_kernel (a lane owns a path) or render_kernel_wf (a wave owns a pool of paths)
+    const bool want_wavefront = cfg.kernel == RT_KERNEL_WAVEFRONT;
+    const uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
+    const int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
     if (guarded) {
         // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
         // spheres for origins within sqrt(d0_sq) of their cluster: a camera outside either gets the tree re-packed
@@ -527,7 +537,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     if (guarded) {
         const uint64_t table_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;      // fp32 pair records when LDS-resident
         const int32_t want = sc->tree_depth + 1 > 2 ? sc->tree_depth + 1 : 2;       // never overflows
-        const uint32_t per_level = rtk::kBlock * 4u;
+        const uint32_t per_level = gblock * 4u;
         // tables in LDS when they leave room for a useful stack at full occupancy; else they are read
         // through L1/L2 and LDS holds only the stacks
         auto levels_for = [&](uint64_t scene_bytes, int wgs_per_cu) -> int32_t {
@@ -537,7 +547,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             return (int32_t)(fit < want ? fit : want);
         };
         const int32_t min_levels = want < 4 ? want : 4;          // a shorter stack flags too many rays
-        fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
+        fast.wgs_per_cu = gwgs_per_cu;
         fast.in_lds = cfg.scene_in_lds != 0;
         if (fast.in_lds) {
             fast.stack_levels = levels_for(table_bytes, fast.wgs_per_cu);
@@ -547,7 +557,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (!fast.in_lds) {
             // tables through L1/L2: a 12-entry stack per lane (deeper ones are rare enough to flag), the rest of
             // the workgroup's LDS share holds the top of the tree
-            fast.wgs_per_cu = RTP_MIN_WAVES * 256 / rtk::kBlock;
+            fast.wgs_per_cu = gwgs_per_cu;
             fast.stack_levels = levels_for(0, fast.wgs_per_cu);
             if (fast.stack_levels > 12) fast.stack_levels = 12;
         }
@@ -568,39 +578,45 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
 #endif
     if (use_queue) guarded = false;
 
-    // Samples per pass: as many as the slab budget admits (default 20 GiB of the 288 GB, RTP_SLAB_GIB),
-    // at least 64, and few enough for the 32-bit work index and its reciprocal-multiply division.
+    // Samples per pass: as many as the workspace budget admits (rt_config.workspace_bytes, default just under 4 GiB;
+    // 12 bytes per sample), at least 64, and few enough for the 32-bit work index and its reciprocal-multiply
+    // division; the passes of a frame are made equally long.
     // Fewer, larger launches amortise the end-of-launch tail — on a row shard of an N-GPU frame
     // the pass grows N-fold, so a launch keeps the size it has on one GPU.
     const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
     int pass_size = P.spp;
+    auto pitch_of = [](int pass) { return (uint32_t)((pass + 3) & ~3); };       // rows of the slab are 16-byte aligned
     {
         const uint64_t budget = cfg.workspace_bytes;
-        uint64_t fit = budget / ((uint64_t)num_pixels * sizeof(float4));
+        uint64_t fit = budget / ((uint64_t)num_pixels * kSampleBytes);
+        fit &= ~(uint64_t)3;
         const uint64_t index_fit = (((uint64_t)1 << 30) - 64) / num_pixels;     // total_work + 64 <= 2^30
         if (fit > index_fit) fit = index_fit;
         if (fit < 64) fit = 64;
-        if ((uint64_t)pass_size > fit) pass_size = (int)fit;
+        if ((uint64_t)pass_size > fit) {
+            const int passes_wanted = (int)((P.spp + fit - 1) / fit);
+            pass_size = (P.spp + passes_wanted - 1) / passes_wanted;
+        }
         if (const int forced = cfg.pass_spp) pass_size = forced < P.spp ? forced : P.spp;
         rtk::Magic probe;
         while (pass_size > 64 && !make_magic((uint32_t)pass_size, (uint64_t)num_pixels * pass_size + 64, probe)) --pass_size;
     }
-    // workspace: one float4 per (local pixel, slot)
-    size_t need = (size_t)num_pixels * (size_t)pass_size;
-    if (sc->slab_float4s < need) {
+    // workspace: three floats per (local pixel, slot)
+    size_t need = (size_t)num_pixels * (size_t)pitch_of(pass_size) * 3;
+    if (sc->slab_floats < need) {
         HIP_TRY(hipStreamSynchronize(stream));
         (void)hipFree(sc->slab);
         sc->slab = nullptr;
-        sc->slab_float4s = 0;
+        sc->slab_floats = 0;
         for (;;) {      // a device short of memory gets shorter passes, not an error
-            const hipError_t e = hipMalloc((void **)&sc->slab, need * sizeof(float4));
+            const hipError_t e = hipMalloc((void **)&sc->slab, need * sizeof(float));
             if (e == hipSuccess) break;
             (void)hipGetLastError();
             if (e != hipErrorOutOfMemory || pass_size <= 64) HIP_TRY(e);
             pass_size = pass_size / 2 < 64 ? 64 : pass_size / 2;
-            need = (size_t)num_pixels * (size_t)pass_size;
+            need = (size_t)num_pixels * (size_t)pitch_of(pass_size) * 3;
         }
-        sc->slab_float4s = need;
+        sc->slab_floats = need;
     }
     P.slab = sc->slab;
     P.num_pixels = num_pixels;
@@ -608,7 +624,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     if (passes > kMaxPasses) return fail(RT_ERR_UNSUPPORTED, "samples_per_pixel above 65536");
     if (guarded) {
         // flagged-sample list: a quarter of a pass's samples (a fuller list means "re-walk everything")
-        const size_t cap = need / 4 + 65536;
+        const size_t cap = (size_t)num_pixels * (size_t)pass_size / 4 + 65536;
         if (sc->flag_cap < cap) {
             HIP_TRY(hipStreamSynchronize(stream));
             (void)hipFree(sc->flag_list);
@@ -619,6 +635,25 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         }
     }
 
+    // kernel form of the guarded pass: render_kernel (a lane owns a path) or render_kernel_wf (a wave owns a pool of paths)
+    const bool wavefront = guarded && want_wavefront && !use_queue;
+    uint32_t wf_target = 0;
+    if (wavefront) {
+        wf_target = (uint32_t)(cfg.wavefront_paths > 0 ? cfg.wavefront_paths : 192);
+        if (wf_target < 128u) wf_target = 128u;              // below that a wave can run dry (rt_kernel_wf.hip.inc)
+        if (wf_target > 4096u) wf_target = 4096u;
+        wf_target = (wf_target + 63u) & ~63u;
+        const size_t waves_total = (size_t)sc->num_cus * fast.wgs_per_cu * (rtk::kWfBlock / rtk::kWave);
+        const size_t need_pool = waves_total * (size_t)(rtk::kWfRayRows + rtk::kWfHitRows) * wf_target;
+        if (sc->wf_pool_float4s < need_pool) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(sc->wf_pool);
+            sc->wf_pool = nullptr;
+            sc->wf_pool_float4s = 0;
+            HIP_TRY(hipMalloc((void **)&sc->wf_pool, need_pool * sizeof(float4)));
+            sc->wf_pool_float4s = need_pool;
+        }
+    }
     const Shape &main_shape = guarded ? fast : exact;
     const uint32_t max_wgs = (uint32_t)(((uint64_t)num_pixels * (P.spp < 64 ? P.spp : 64) + rtk::kBlock - 1) / rtk::kBlock);
     auto grid_for = [&](const Shape &sh) {
@@ -634,6 +669,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kBlock), lds, stream, KP);
+        return hipGetLastError();
+    };
+    auto launch_wf = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kWfBlock), lds, stream, KP);
         return hipGetLastError();
     };
     auto launch_exact = [&](rtk::KParams &KP, int grid) -> hipError_t {
@@ -688,6 +729,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         P.pass_first = pass * pass_size;
         P.pass_count = P.spp - P.pass_first < pass_size ? P.spp - P.pass_first : pass_size;
         P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
+        P.slab_pitch = pitch_of(pass_size);
         if (!make_magic((uint32_t)P.pass_count, (uint64_t)P.total_work + 64, P.magic_count))
             return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");
         P.queue = sc->queue + kQueueWork + pass;
@@ -696,7 +738,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         // with an atomic per 64 samples was the bottleneck of the whole kernel (5.05 -> 6.25 Gsamples/s with
         // 512 per atomic); small frames keep at least 16 reservations per wave so the tail stays balanced.
         {
-            const uint64_t waves_total = (uint64_t)wgs * (rtk::kBlock / rtk::kWave);
+            const uint64_t waves_total = (uint64_t)wgs * ((wavefront ? rtk::kWfBlock : rtk::kBlock) / rtk::kWave);
             uint64_t per = (uint64_t)P.total_work / (waves_total * 16u * 64u);
             per = per < 1 ? 1 : (per > 8 ? 8 : per);
             if (const int forced = cfg.reserve_chunk) per = (uint64_t)(forced > 0 ? forced : 1);
@@ -721,7 +763,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
             if (const uint32_t tiny = cfg.flag_capacity) P.flag_cap = tiny < P.flag_cap ? tiny : P.flag_cap;   // test hook: overflow path
-            if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
+            if (wavefront) {
+                P.wf_pool = sc->wf_pool;
+                P.wf_cap = P.wf_target = wf_target;
+                P.wf_k_exchange = cfg.wavefront_exchange > 0 ? (cfg.wavefront_exchange > 64 ? 64 : cfg.wavefront_exchange) : 16;
+                if (fast.in_lds) HIP_TRY(launch_wf(rtk::render_kernel_wf<true>, P, wgs, fast.lds_bytes));
+                else HIP_TRY(launch_wf(rtk::render_kernel_wf<false>, P, wgs, fast.lds_bytes));
+            } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
             else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
             if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
             // … and are walked again in the reference's order, overwriting their slab entries
@@ -743,14 +791,14 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         }
         // … then added to the pixel sums strictly in sample order
         hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 255) / 256), dim3(256), 0, stream, d_fb_sum,
-                           (const float4 *)sc->slab, num_pixels, P.pass_count, pass == 0 ? 1 : 0);
+                           (const float *)sc->slab, num_pixels, P.slab_pitch, P.pass_count, pass == 0 ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_stop, stream));
     sc->timed = true;
     sc->last = rt_timing{};
     sc->last.num_workgroups = (uint32_t)wgs;
-    sc->last.workgroup_size = rtk::kBlock;
+    sc->last.workgroup_size = wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;
     sc->last.lds_bytes = main_shape.lds_bytes;
 #ifdef RTP_DEV_QUEUE_KERNEL
     if (use_queue) { sc->last.workgroup_size = rtk::kQBlock; sc->last.lds_bytes = q_lds; }
@@ -760,7 +808,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last.trace_launches = (uint32_t)passes;
     sc->last.guarded = guarded ? 1u : 0u;
     sc->last.guard_unproven = (guarded && gamma_unproven(cfg)) ? 1u : 0u;
-    sc->last.kernel = RT_KERNEL_MEGA;
+    sc->last.kernel = wavefront ? RT_KERNEL_WAVEFRONT : RT_KERNEL_MEGA;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);
@@ -800,7 +848,7 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
         }
         uint32_t abort_code = 0;
         HIP_TRY(hipMemcpy(&abort_code, sc->queue + kQueueStats + 15, 4, hipMemcpyDeviceToHost));
-        if (abort_code != 0) return fail(RT_ERR_HIP, "render_kernel_q aborted (queue protocol timeout, code " + std::to_string(abort_code) + ")");
+        if (abort_code != 0) return fail(RT_ERR_HIP, "render kernel aborted (protocol timeout, code " + std::to_string(abort_code) + ")");
     }
     if (timing) *timing = sc->last;
     return RT_OK;

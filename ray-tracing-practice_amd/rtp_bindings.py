@@ -77,7 +77,8 @@ class Config(C.Structure):
                 ("guard_keep", C.c_int32), ("guard_repack", C.c_int32), ("kernel", C.c_int32), ("workspace_bytes", C.c_uint64),
                 ("pass_spp", C.c_int32), ("stack_levels", C.c_int32), ("flag_capacity", C.c_uint32), ("scene_in_lds", C.c_int32),
                 ("lds_treelet", C.c_int32), ("workgroups_per_cu", C.c_int32), ("k_inner", C.c_int32), ("k_shade", C.c_int32),
-                ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32)]
+                ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
+                ("wavefront_exchange", C.c_int32)]
 
 
 class ConfigInfo(C.Structure):

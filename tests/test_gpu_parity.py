@@ -357,6 +357,39 @@ def test_alternative_kernels_agree_with_default(rtiow):
         dev.configure(traversal=rb.TRAVERSAL_AUTO)
 
 
+def test_wavefront_kernel_gives_the_same_frames():
+    """rt_config.kernel = RT_KERNEL_WAVEFRONT (rt_kernel_wf.hip.inc: a wave owns a pool of paths in wave-private L2-resident
+    stacks and alternates dense SHADE / GENERATE / EXCHANGE / TRACE steps) — same bits as the oracle: S-rtiow at several
+    pool sizes and exchange thresholds, a frame smaller than one wave's pool, the config scene (planes, lights,
+    absorbing glass), a far camera (far-origin flags) and a 2-entry traversal stack (many flagged samples)."""
+    host = rb.HostScene.rtiow()
+    cam = rb.rtiow_camera(200, 120, 12, 50)
+    want = ob.render(host, cam, threads=8)
+    for paths, exch in ((0, 0), (128, 4), (512, 32), (192, 64)):
+        dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT, wavefront_paths=paths, wavefront_exchange=exch)
+        fb, t = dev.render_to_host(cam)
+        assert t.kernel == rb.KERNEL_WAVEFRONT and t.guarded == 1
+        assert_same_frame(fb, want, f"wavefront kernel, pool {paths}, exchange {exch}")
+    dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT)
+    tiny = rb.rtiow_camera(7, 5, 3, 50)
+    fb, t = dev.render_to_host(tiny)
+    assert_same_frame(fb, ob.render(host, tiny, threads=4), "wavefront kernel, 105 samples in all")
+    far = rb.make_camera(160, 90, 3.0, (400.0, 90.0, 60.0), (0, 0, 0), (0.7, 0.8, 1.0), 4, 50)
+    dev.configure(guard_repack=0, stack_levels=2, guard_keep=1)
+    fb, t = dev.render_to_host(far)
+    assert t.kernel == rb.KERNEL_WAVEFRONT and t.flagged_samples > 1000
+    assert_same_frame(fb, ob.render(host, far, threads=8), "wavefront kernel, far camera, 2-entry stack")
+
+
+def test_wavefront_kernel_on_the_config_scene(config_scene):
+    host, _ = config_scene
+    dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
+    cam = host.frame_camera(0)
+    fb, t = dev.render_to_host(cam)
+    assert t.kernel == rb.KERNEL_WAVEFRONT and t.guarded == 1
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "wavefront kernel, config scene")
+
+
 def test_config_api_without_environment():
     """A handle created with honour_env=False takes everything from rt_config: forced pass size, a capped stack,
     an opt-in unproven margin (reported in rt_timing.guard_unproven) — frames are the oracle's in every case."""
@@ -371,10 +404,10 @@ def test_config_api_without_environment():
     fb, t = dev2.render_to_host(cam)
     assert t.guarded == 1 and t.guard_unproven == 1
     assert_same_frame(fb, want, "guard_gamma_ulps=8 (opt-in, unproven)")
-    dev3 = rb.DeviceScene(host, device=0, honour_env=False, workspace_bytes=160 * 90 * 16 * 64)
+    dev3 = rb.DeviceScene(host, device=0, honour_env=False, workspace_bytes=160 * 90 * 12 * 64)
     fb, t = dev3.render_to_host(cam)
     assert t.trace_launches == 2
-    assert_same_frame(fb, want, "workspace for 64 spp per pass")
+    assert_same_frame(fb, want, "workspace for 64 spp per pass: two passes of 35")
 
 
 def test_guarded_walk_flags_and_rewalks(rtiow, force_guarded):
