@@ -270,6 +270,32 @@ rt_status rt_copy_to_host(void *host_dst, const void *device_src, uint64_t bytes
 rt_status rt_tonemap(const float *d_fb_sum, uint8_t *d_rgb8, int64_t num_floats, int32_t divisor,
                      void *hip_stream);
 
+/* ---- multi-GPU: one frame sharded over the GPUs of one node ------------------------------------------
+ * The reference has no multi-GPU path (src/camera.cu:290-349 renders on the current device).  A context owns, per
+ * device, a stream, a replica of the scene, that device's rows of the frame and an RCCL communicator (single
+ * process; RCCL is bound at run time and only needed for more than one device).  rt_render_sharded() renders the
+ * interleaved row bands (band b → device b % N, as rt_shard) on all devices concurrently and rt_gather()s them:
+ * ONE grouped ncclSend per device / ncclRecv on the root over xGMI, then the root puts the bands at their image rows.
+ * The assembled frame is bit-identical to a one-device rt_render.  One host thread drives a context. */
+typedef struct rt_context rt_context;
+
+/* num_devices <= 0: every GPU of the node.  device_ordinals NULL: 0 … num_devices-1.  The first device is the root. */
+rt_status rt_context_create(int32_t num_devices, const int32_t *device_ordinals, rt_context **out_ctx);
+rt_status rt_context_destroy(rt_context *ctx);
+int32_t rt_context_num_devices(const rt_context *ctx);
+/* "rccl" (ncclSend/ncclRecv, also for a one-device context when librccl is present), "local" (one device, no RCCL) or
+ * "copy" (device_ordinals lists a device more than once — a rehearsal of an N-way shard on fewer GPUs: the rows move
+ * with device copies, RCCL does not admit one GPU twice). */
+const char *rt_context_transport(const rt_context *ctx);
+/* rt_scene_create_ex on every device of the context (replaces the context's previous scene). */
+rt_status rt_context_scene_create(rt_context *ctx, const rt_scene_desc *desc, const rt_config *cfg);
+/* Camera::render for the whole node: d_fb_sum_root is image_height*image_width*3 floats on the ROOT device; returns
+ * when the assembled frame is there.  band_rows <= 0: 8.  timings: NULL or num_devices entries (per-device rt_timing). */
+rt_status rt_render_sharded(rt_context *ctx, const rt_camera_data *cam, int32_t band_rows, float *d_fb_sum_root,
+                            rt_timing *timings);
+/* The collective alone: assembles the rows the devices hold from the last rt_render_sharded of this geometry. */
+rt_status rt_gather(rt_context *ctx, int32_t image_width, int32_t image_height, int32_t band_rows, float *d_fb_sum_root);
+
 /* Thread-local text of the last failing call ("" if none). */
 const char *rt_get_last_error_string(void);
 

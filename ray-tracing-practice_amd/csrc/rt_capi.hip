@@ -287,6 +287,9 @@ rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream
 
 }  // namespace
 
+// for rt_multi.hip (same library, not exported)
+__attribute__((visibility("hidden"))) void rt_internal_set_error(const std::string &msg) { g_last_error = msg; }
+
 extern "C" {
 
 const char *rt_get_last_error_string(void) { return g_last_error.c_str(); }

@@ -124,4 +124,8 @@ void gpu_render(const SceneParams &params);
 // arithmetic on the device, file output overlapped with the next frame.  Same files, byte for byte.
 void gpu_render_pipelined(const SceneParams &params, const rt_scene_desc &desc, int num_devices);
 
+// … and the other split: every frame sharded in row bands over num_devices GPUs (<= 0: all) with one RCCL gather per
+// frame (rt_context, rt_render_sharded).  Same files, byte for byte.
+void gpu_render_sharded(const SceneParams &params, const rt_scene_desc &desc, int num_devices);
+
 }  // namespace rtp

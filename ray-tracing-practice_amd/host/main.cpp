@@ -34,6 +34,12 @@ int main(int argc, char *argv[]) {
     if (const char *env = getenv("RTP_DEVICES")) devices = atoi(env);
     for (int a = 2; a + 1 < argc; ++a)
         if (std::string(argv[a]) == "--devices") devices = atoi(argv[a + 1]);
+    // extension: `--gpu --shard N` splits EVERY frame over N GPUs (0 = all of the node) with one RCCL gather per frame
+    for (int a = 2; a + 1 < argc; ++a)
+        if (std::string(argv[a]) == "--shard") {
+            rtp::gpu_render_sharded(params, desc, atoi(argv[a + 1]));
+            return 0;
+        }
     if (devices > 0) {
         rtp::gpu_render_pipelined(params, desc, devices);
         return 0;

@@ -179,4 +179,52 @@ void gpu_render_pipelined(const SceneParams &params, const rt_scene_desc &desc, 
     for (std::thread &t : threads) t.join();
 }
 
+// ---- one frame over all GPUs (BASELINE configs[3]) ------------------------------------------
+// The other way to use a node: every frame is split into interleaved 8-row bands over `num_devices` GPUs
+// (rt_context / rt_render_sharded: scene replicated, one RCCL gather per frame to the root GPU), then the root runs
+// the saver arithmetic on the device and the file is written while the next frame renders.  Same files, byte for byte.
+void gpu_render_sharded(const SceneParams &params, const rt_scene_desc &desc, int num_devices) {
+    rt_context *ctx = nullptr;
+    RTP_CHECK(rt_context_create(num_devices, nullptr, &ctx));
+    RTP_CHECK(rt_context_scene_create(ctx, &desc, nullptr));
+    const int n = rt_context_num_devices(ctx);
+    const size_t num_pixels = static_cast<size_t>(params.width) * params.height;
+    float *d_fb = nullptr;
+    uint8_t *d_rgb = nullptr;
+    RTP_CHECK(rt_set_device(0));
+    RTP_CHECK(rt_device_alloc(num_pixels * 3 * sizeof(float), reinterpret_cast<void **>(&d_fb)));
+    RTP_CHECK(rt_device_alloc(num_pixels * 3, reinterpret_cast<void **>(&d_rgb)));
+    std::thread writer;
+    std::vector<rt_timing> timings(static_cast<size_t>(n));
+    for (int f = 0; f < params.num_frames; ++f) {
+        const std::string filename = frame_filename(params.output_pattern, f);
+        Vec3 eye, target;
+        orbit_pose(params, f, eye, target);
+        Camera camera(params.height, params.width, nullptr, eye, target);
+        camera.vfov = params.fov_degrees;
+        camera.samples_per_pixel = params.sqrt_spp * params.sqrt_spp;
+        camera.max_depth = params.max_depth;
+        camera.background_color = Vec3(0, 0, 0);
+        const rt_camera_data cam = camera.build_camera_data();
+        const auto t0 = std::chrono::steady_clock::now();
+        RTP_CHECK(rt_render_sharded(ctx, &cam, 8, d_fb, timings.data()));
+        RTP_CHECK(rt_tonemap(d_fb, d_rgb, static_cast<int64_t>(num_pixels) * 3, params.sqrt_spp, nullptr));
+        auto file = std::make_shared<PendingFile>();
+        file->path = filename;
+        file->width = params.width;
+        file->height = params.height;
+        file->rgb.resize(num_pixels * 3);
+        RTP_CHECK(rt_copy_to_host(file->rgb.data(), d_rgb, num_pixels * 3));
+        if (writer.joinable()) writer.join();
+        writer = std::thread([file]() { write_binary_frame(*file); });
+        const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const long long total_rays = static_cast<long long>(params.width) * params.height * params.sqrt_spp * params.sqrt_spp;
+        std::cout << f << "\t" << ms << "\t" << total_rays << "\n";
+    }
+    if (writer.joinable()) writer.join();
+    rt_device_free(d_fb);
+    rt_device_free(d_rgb);
+    RTP_CHECK(rt_context_destroy(ctx));
+}
+
 }  // namespace rtp

@@ -96,6 +96,8 @@ RTP_AMD_SYMBOLS = [
     "rt_last_timing",
     "rt_render_to_host", "rt_trace_samples", "rt_closest_hits", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
     "rt_get_last_error_string", "rt_version_string",
+    "rt_context_create", "rt_context_destroy", "rt_context_num_devices", "rt_context_transport", "rt_context_scene_create",
+    "rt_render_sharded", "rt_gather",
 ]
 
 _host = None
@@ -168,6 +170,14 @@ def amd_lib():
         lib.rt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         lib.rt_get_last_error_string.restype = C.c_char_p
         lib.rt_version_string.restype = C.c_char_p
+        lib.rt_context_create.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+        lib.rt_context_destroy.argtypes = [C.c_void_p]
+        lib.rt_context_num_devices.argtypes = [C.c_void_p]
+        lib.rt_context_transport.argtypes = [C.c_void_p]
+        lib.rt_context_transport.restype = C.c_char_p
+        lib.rt_context_scene_create.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(Config)]
+        lib.rt_render_sharded.argtypes = [C.c_void_p, C.POINTER(CameraData), C.c_int32, C.c_void_p, C.POINTER(Timing)]
+        lib.rt_gather.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         _amd = lib
     return _amd
 
@@ -365,6 +375,49 @@ class DeviceScene:
     def close(self):
         if self._h:
             amd_lib().rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """rt_context: one frame sharded over the GPUs of the node through the C ABI (rt_render_sharded + rt_gather)."""
+
+    def __init__(self, num_devices=0, ordinals=None):
+        self._h = C.c_void_p()
+        arr = (C.c_int32 * len(ordinals))(*ordinals) if ordinals else None
+        _check(amd_lib().rt_context_create(num_devices, arr, C.byref(self._h)), "rt_context_create")
+        self._keep = None
+
+    @property
+    def num_devices(self):
+        return amd_lib().rt_context_num_devices(self._h)
+
+    @property
+    def transport(self):
+        return amd_lib().rt_context_transport(self._h).decode()
+
+    def scene(self, host_scene, **config):
+        cfg = Config()
+        amd_lib().rt_config_init(C.byref(cfg))
+        for k, v in config.items():
+            setattr(cfg, k, v)
+        _check(amd_lib().rt_context_scene_create(self._h, C.byref(host_scene.desc), C.byref(cfg)), "rt_context_scene_create")
+        self._keep = host_scene
+
+    def render(self, cam, d_fb_ptr, band_rows=8):
+        """d_fb_ptr: device address on the root device of image_height*image_width*3 floats.  Returns the per-device timings."""
+        t = (Timing * self.num_devices)()
+        _check(amd_lib().rt_render_sharded(self._h, C.byref(cam), band_rows, C.c_void_p(d_fb_ptr), t), "rt_render_sharded")
+        return list(t)
+
+    def close(self):
+        if self._h:
+            amd_lib().rt_context_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -323,7 +323,7 @@ def test_cli_frame_drivers_write_reference_bytes(test_config_text, golden, tmp_p
     # (b) a 3-frame orbit, both drivers
     lines[0] = "3"
     lines[5] = "0.0 0.0 1.0"          # wrc wzc wc: the eye circles the scene
-    for tag, extra in (("seq", []), ("pipe", ["--devices", "1"])):
+    for tag, extra in (("seq", []), ("pipe", ["--devices", "1"]), ("shard", ["--shard", "1"])):
         lines[1] = str(tmp_path / (tag + "_%d.png"))
         out = subprocess.run([exe, "--gpu"] + extra, input="\n".join(lines), capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
@@ -332,7 +332,8 @@ def test_cli_frame_drivers_write_reference_bytes(test_config_text, golden, tmp_p
     for f in range(3):
         a = open(tmp_path / f"seq_{f}.png", "rb").read()
         b = open(tmp_path / f"pipe_{f}.png", "rb").read()
-        assert a == b and len(a) == 60008
+        c = open(tmp_path / f"shard_{f}.png", "rb").read()        # rt_context / rt_render_sharded / RCCL self gather
+        assert a == b and a == c and len(a) == 60008
         cam = host.frame_camera(f)
         want = rb.binary_image_bytes(ob.render(host, cam, threads=4), 200, 100, host.info.sqrt_spp)
         assert a == want
@@ -388,6 +389,34 @@ def test_wavefront_kernel_on_the_config_scene(config_scene):
     fb, t = dev.render_to_host(cam)
     assert t.kernel == rb.KERNEL_WAVEFRONT and t.guarded == 1
     assert_same_frame(fb, ob.render(host, cam, threads=8), "wavefront kernel, config scene")
+
+
+def test_context_renders_sharded_frames_through_the_c_abi():
+    """rt_context / rt_render_sharded / rt_gather: (a) a one-device context — the gather runs through RCCL
+    (ncclSend/ncclRecv to itself: the code path of an 8-GPU node, transport "rccl") and the frame is the oracle's;
+    (b) the same device listed 2 and 3 times ("copy" transport: RCCL does not admit one GPU twice): interleaved bands of
+    4 and 8 rows with ragged ends, rendered as separate shards on separate streams and reassembled — bit-identical."""
+    import torch
+    host = rb.HostScene.rtiow()
+    cam = rb.rtiow_camera(200, 117, 5, 50)             # 117 rows: the last band is partial
+    want = ob.render(host, cam, threads=8)
+    fb = torch.empty((117, 200, 3), dtype=torch.float32, device="cuda:0")
+    ctx = rb.Context(1)
+    assert ctx.num_devices == 1 and ctx.transport == "rccl"
+    ctx.scene(host)
+    ts = ctx.render(cam, fb.data_ptr())
+    assert len(ts) == 1 and ts[0].kernel_ms > 0
+    assert_same_frame(fb.cpu().numpy(), want, "one-device context, RCCL self gather")
+    ctx.close()
+    for parts, band in ((2, 8), (3, 4)):
+        ctx = rb.Context(parts, ordinals=[0] * parts)
+        assert ctx.num_devices == parts and ctx.transport == "copy"
+        ctx.scene(host)
+        fb.zero_()
+        ts = ctx.render(cam, fb.data_ptr(), band_rows=band)
+        assert len(ts) == parts
+        assert_same_frame(fb.cpu().numpy(), want, f"{parts}-way shard of one GPU, bands of {band}")
+        ctx.close()
 
 
 def test_config_api_without_environment():
