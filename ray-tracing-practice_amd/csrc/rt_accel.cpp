@@ -514,16 +514,24 @@ void Packer::prepare_guard() {
                     const float cam[3] = {camera_hint[0], camera_hint[1], camera_hint[2]};
                     reach = std::max(reach, 1.25 * (dist(sc, cam) + rs));
                 }
-                // tiny spheres scattered over a large volume: the margin (∝ reach^2 / r) swallows the tree
-                if (gamma * reach * reach / (2.0 * r_min_small) > 64.0 * r_min_small) why = "margins exceed 64 radii for the smallest spheres";
+                // One margin per sphere has to cover the farthest admissible origin: for tiny spheres spread over a wide
+                // volume it (∝ reach^2 / r) approaches or exceeds the radius and swallows the tree (S-100k with the proven
+                // gamma: 3.6 radii — the walk then does more work than the reference's).  Such scenes get DISTANCE-AWARE
+                // margins instead: the leaves keep only the rounding floor and the walk grows every box it tests by
+                // dyn_k * (distance from the ray's own origin to the box's farthest corner)^2, which bounds
+                // gamma |o - c_q|^2 / (2 r_q) for every small sphere q below the box, wherever the ray starts.
+                const double eps_static = gamma * reach * reach / (2.0 * r_min_small);
+                const bool dynamic = opt.dynamic == 2 || (opt.dynamic == 0 && eps_static > 0.25 * r_min_small);
+                if (!dynamic && eps_static > 64.0 * r_min_small) why = "margins exceed 64 radii for the smallest spheres";
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)
                     if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)])
-                        eps[static_cast<size_t>(i)] = gamma * reach * reach / (2.0 * d.spheres[i].radius);
+                        eps[static_cast<size_t>(i)] = dynamic ? 0.0 : gamma * reach * reach / (2.0 * d.spheres[i].radius);
                 for (int a = 0; a < 3; ++a) g.center[a] = static_cast<float>(sc[a]);
-                g.d0_sq = static_cast<float>(d0 * d0 * (1.0 - 1e-6));
+                g.d0_sq = dynamic ? INFINITY : static_cast<float>(d0 * d0 * (1.0 - 1e-6));      // dynamic: no far-origin test needed
                 g.cluster_radius = static_cast<float>(rs * (1.0 + 1e-6));
                 g.far_k = static_cast<float>(gamma / (2.0 * r_min_small) * (1.0 + 1e-6));
+                g.dyn_k = dynamic ? static_cast<float>(gamma / (2.0 * r_min_small) * (1.0 + 4e-6)) : 0.0f;
                 for (int i = 0; i < d.num_spheres; ++i) {
                     if (leaf_of_sphere[static_cast<size_t>(i)] < 0 || large[static_cast<size_t>(i)]) continue;
                     const float *b = d.nodes[leaf_of_sphere[static_cast<size_t>(i)]].box;

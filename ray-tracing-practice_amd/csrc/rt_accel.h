@@ -61,6 +61,10 @@ struct Packed {
         float cluster_radius = 0;      // class S spheres lie within this distance of the centre
         float box[6] = {0, 0, 0, 0, 0, 0};   // their bounding box (x.min x.max y.min y.max z.min z.max)
         float far_k = 0;               // far-origin inflation of that box: far_k * (|o - centre| + cluster_radius)^2
+        // Distance-aware margins (0 = off): the small spheres' leaf boxes carry only the rounding floor and every box
+        // test of the walk grows its box by dyn_k * (distance from the ray origin to the box's farthest corner)^2
+        // >= gamma |o - c_q|^2 / (2 r_q) for every small sphere q below — no assumption about where rays start.
+        float dyn_k = 0;
         int32_t num_small = 0, num_large = 0;
         // every margin assumes ray origins within origin_radius of origin_center (all scene surfaces +
         // 25 %): the camera position is checked against it per render
@@ -88,6 +92,8 @@ constexpr float kGuardGammaObserved = 8.0f * 5.9604645e-8f;
 struct PackOptions {
     double gamma = kGuardGammaBound;   // discriminant error budget the leaf margins cover
     bool leaf_table = false;           // always emit the exact sphere leaf boxes as a table (developer)
+    int dynamic = 0;                   // distance-aware margins for the small spheres: 0 = where static ones would exceed a
+                                       // quarter of the smallest radius, 1 = never, 2 = always
 };
 
 // binary16 helpers of the half-precision node table (exposed for the native test)

@@ -96,6 +96,7 @@ rt_config config_from_caller(const rt_config *in) {
 
 rtaccel::PackOptions pack_options(const rt_config &cfg) {
     rtaccel::PackOptions o;
+    o.dynamic = cfg.guard_dynamic_margins;
     if (cfg.guard_gamma_ulps > 0.0f) o.gamma = (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8;
     o.leaf_table = cfg.guard_exact_leaf_table != 0;
     return o;
@@ -237,6 +238,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.g_d0sq = sc->guard.d0_sq;
     P.g_rs = sc->guard.cluster_radius;
     P.g_fark = sc->guard.far_k;
+    P.g_dynk = sc->guard.dyn_k;
     std::memcpy(P.g_box, sc->guard.box, 24);
     P.k_inner = sc->cfg.k_inner > 0 ? sc->cfg.k_inner : 24;
     P.k_shade = sc->cfg.k_shade > 0 ? sc->cfg.k_shade : 48;
@@ -318,6 +320,7 @@ void rt_config_from_env(rt_config *cfg) {
     if (str_is("RTP_KERNEL", "wavefront")) cfg->kernel = RT_KERNEL_WAVEFRONT;
     if (const char *v = getenv("RTP_GUARD_GAMMA_ULPS")) cfg->guard_gamma_ulps = (float)atof(v);
     cfg->guard_exact_leaf_table = env_int("RTP_GUARD_TABLE", cfg->guard_exact_leaf_table);
+    cfg->guard_dynamic_margins = env_int("RTP_GUARD_DYNAMIC", cfg->guard_dynamic_margins);
     cfg->guard_min_primitives = env_int("RTP_GUARD_MIN_PRIMS", cfg->guard_min_primitives);
     cfg->guard_keep = env_int("RTP_GUARD_KEEP", cfg->guard_keep);
     if (env_int("RTP_NO_REPACK", 0)) cfg->guard_repack = 0;
@@ -345,6 +348,7 @@ rt_status rt_scene_set_config(rt_scene *sc, const rt_config *cfg) {
     c.tree_build = sc->cfg.tree_build;
     c.guard_gamma_ulps = sc->cfg.guard_gamma_ulps;
     c.guard_exact_leaf_table = sc->cfg.guard_exact_leaf_table;
+    c.guard_dynamic_margins = sc->cfg.guard_dynamic_margins;
     sc->cfg = c;
     return RT_OK;
 }
@@ -639,7 +643,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     }
 
     // kernel form of the guarded pass: render_kernel (a lane owns a path) or render_kernel_wf (a wave owns a pool of paths)
-    const bool wavefront = guarded && want_wavefront && !use_queue;
+    const bool dyn = guarded && sc->guard.dyn_k > 0.0f;                     // distance-aware margins (big or widely spread scenes)
+    const bool wavefront = guarded && want_wavefront && !use_queue && !dyn;
     uint32_t wf_target = 0;
     if (wavefront) {
         wf_target = (uint32_t)(cfg.wavefront_paths > 0 ? cfg.wavefront_paths : 192);
@@ -772,6 +777,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
                 P.wf_k_exchange = cfg.wavefront_exchange > 0 ? (cfg.wavefront_exchange > 64 ? 64 : cfg.wavefront_exchange) : 16;
                 if (fast.in_lds) HIP_TRY(launch_wf(rtk::render_kernel_wf<true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch_wf(rtk::render_kernel_wf<false>, P, wgs, fast.lds_bytes));
+            } else if (dyn) {
+                if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
+                else HIP_TRY(launch(rtk::render_kernel<false, false, true>, P, wgs, fast.lds_bytes));
             } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
             else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
             if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
@@ -812,6 +820,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last.guarded = guarded ? 1u : 0u;
     sc->last.guard_unproven = (guarded && gamma_unproven(cfg)) ? 1u : 0u;
     sc->last.kernel = wavefront ? RT_KERNEL_WAVEFRONT : RT_KERNEL_MEGA;
+    sc->last.guard_dynamic = dyn ? 1u : 0u;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);

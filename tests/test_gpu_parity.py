@@ -419,6 +419,36 @@ def test_context_renders_sharded_frames_through_the_c_abi():
         ctx.close()
 
 
+def test_distance_aware_margins():
+    """rt_config.guard_dynamic_margins: (a) forced on S-rtiow (LDS-resident tables: render_kernel<true,false,true>), near
+    and very far cameras — no far-origin flags, no re-pack needed; (b) tiny spheres scattered over a wide volume, a
+    scene whose static margins would exceed 64 radii (not eligible for the guarded walk before) now walks guarded;
+    frames are the oracle's."""
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=2)
+    for cam in (rb.rtiow_camera(240, 135, 8, 50), rb.make_camera(160, 90, 3.0, (400.0, 90.0, 60.0), (0, 0, 0), (0.7, 0.8, 1.0), 4, 50)):
+        fb, t = dev.render_to_host(cam)
+        assert t.guarded == 1 and t.guard_dynamic == 1 and t.scene_in_lds == 1
+        assert_same_frame(fb, ob.render(host, cam, threads=8), "S-rtiow, distance-aware margins")
+    rng = np.random.default_rng(4242)
+    mats = [_material(0, albedo=(0.8, 0.7, 0.6)), _material(1, albedo=(0.9, 0.9, 0.8), fuzz=0.05), _material(2, ir=1.5)]
+    n = 3000
+    spheres = np.zeros((n, 5), dtype=np.float32)
+    spheres[:, :3] = rng.uniform(-400, 400, (n, 3))
+    spheres[:, 3] = rng.uniform(0.02, 0.6, n)
+    spheres[:, 4] = rng.integers(0, 3, n)
+    spheres[0] = [0, 0, -2000, 1600, 0]
+    host = rb.HostScene.from_arrays(spheres, np.zeros((0, 11), np.float32), mats)
+    static = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=1)
+    assert "margins exceed" in static.guard_reason()
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    assert dev.guard_reason() == ""
+    cam = rb.make_camera(320, 180, 50.0, (300, -250, 120), (0, 0, 0), (0.6, 0.7, 0.9), 4, 30)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.guard_dynamic == 1
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "scattered tiny spheres, distance-aware margins")
+
+
 def test_config_api_without_environment():
     """A handle created with honour_env=False takes everything from rt_config: forced pass size, a capped stack,
     an opt-in unproven margin (reported in rt_timing.guard_unproven) — frames are the oracle's in every case."""
@@ -646,16 +676,21 @@ def test_guarded_walk_random_sphere_scenes(force_guarded):
     assert eligible >= 6 and walked_guarded >= 4, (eligible, walked_guarded)
 
 
-def test_stress_scene_at_4k_rows():
-    """BASELINE configs[4] geometry: ~100k spheres + a textured quad at 3840x2160 (2 spp here);
-    index arithmetic at full size (8.3 M pixels, 531 M work indices) and rows against the oracle."""
+def test_stress_scene_whole_4k_frame():
+    """BASELINE configs[4] geometry: ~100k spheres + a textured quad at 3840x2160, 2 spp: the WHOLE frame (8.3 M
+    pixels, 16.6 M samples, index arithmetic at full size) against the oracle, through the default path (guarded walk
+    with the proven margin, tables read through L1/L2) and through the exact walk alone."""
     host = rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=256)
-    dev = rb.DeviceScene(host, device=0)
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
     cam = rb.rtiow_camera(3840, 2160, 2, 50)
+    want = ob.render(host, cam, threads=16)
     fb, t = dev.render_to_host(cam)
-    assert t.scene_in_lds == 0
-    for row in (5, 1080, 2100):
-        assert_same_frame(fb[row:row + 1], ob.render(host, cam, row0=row, row1=row + 1, threads=8), f"4K row {row}")
+    assert t.scene_in_lds == 0 and t.guarded == 1 and t.guard_unproven == 0 and t.guard_dynamic == 1
+    assert_same_frame(fb, want, "4K frame, guarded walk with distance-aware margins")
+    dev.configure(traversal=rb.TRAVERSAL_EXACT)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 0
+    assert_same_frame(fb, want, "4K frame, exact walk")
 
 
 def _random_scene(rng, n_spheres, n_planes, axis_aligned=False):

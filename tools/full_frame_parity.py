@@ -8,6 +8,11 @@ if os.environ.get('SCENE')=='default':      # the reference's `main --default` a
     cam=host.frame_camera(int(os.environ.get('FRAME',0)))
     W,H,SPP=cam.image_width,cam.image_height,cam.samples_per_pixel
     label=f'reference default config frame {os.environ.get("FRAME",0)}: polyhedra scene {W}x{H} {SPP} spp depth {cam.max_depth}'
+elif os.environ.get('SCENE')=='c5':         # BASELINE configs[4]: ~100k spheres + textured quad at 4K, SPP samples (default 16)
+    W,H,SPP=3840,2160,int(os.environ.get('SPP',16))
+    host=rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=2048)
+    cam=rb.rtiow_camera(W,H,SPP,50)
+    label=f'S-100k (99857 spheres + textured quad) {W}x{H} {SPP} spp 50 bounces'
 else:
     W,H,SPP=1920,1080,int(os.environ.get('SPP',500))
     host=rb.HostScene.rtiow()
@@ -31,6 +36,6 @@ for r0 in range(0,H,60):
     bad+=int((~eq).sum()); maxabs=max(maxabs,float(np.abs(want-g).max()))
     print('rows',r0,'bad so far',bad,'elapsed %.0fs'%(time.time()-t), flush=True)
 res={'config':label,'pixels':W*H,'samples':W*H*SPP,'pixels_differing':bad,'max_abs_diff':maxabs,
-     'gpu_kernel_ms':tm.kernel_ms,'guarded_walk':int(tm.guarded),'flagged_samples':int(tm.flagged_samples),'oracle_seconds':time.time()-t,'frame_sha256':hashlib.sha256(got.tobytes()).hexdigest()}
+     'gpu_kernel_ms':tm.kernel_ms,'guarded_walk':int(tm.guarded),'guard_unproven':int(tm.guard_unproven),'trace_launches':int(tm.trace_launches),'flagged_samples':int(tm.flagged_samples),'oracle_seconds':time.time()-t,'frame_sha256':hashlib.sha256(got.tobytes()).hexdigest()}
 print(json.dumps(res))
 json.dump(res,open('gpurun_out/full_frame_parity_%s%s.json'%(os.environ.get('SCENE','rtiow'),'' if os.environ.get('VIEW','headline')=='headline' else '_'+os.environ['VIEW']),'w'),indent=1)

@@ -158,12 +158,26 @@ static unsigned long long n_far, n_far_flag;
 static float g_bs[6], g_rs, g_fark;
 static int g_levels = 64;
 static float *g_rmax;            /* per SAH node: largest radius below */
+/* DYN=1: distance-aware margins (DESIGN.md §3b "dynamic margins"): the small spheres' leaf boxes carry only the
+ * rounding floor, and every box test of the walk grows the box by g_dynk * (distance from the ray origin to the
+ * box's farthest corner)^2 — an upper bound of gamma |o - c_q|^2 / (2 r_q) for every small sphere q below. */
+static int g_dyn = 0;
+static float g_dynk = 0;
+static inline int box_test(const float box[6], const ray *r, float tmin, float tmax, float *enter) {
+    if (!g_dyn) return g_fused ? aabb_hit_fused(box, r, tmin, tmax, enter) : aabb_hit_e(box, r, tmin, tmax, enter);
+    float d2 = 0;
+    for (int a = 0; a < 3; a++) { const float m = fmaxf(fabsf(r->o.e[a] - box[2 * a]), fabsf(box[2 * a + 1] - r->o.e[a])); d2 = fmaf(m, m, d2); }
+    const float E = g_dynk * d2;
+    float g[6];
+    for (int a = 0; a < 3; a++) { g[2 * a] = box[2 * a] - E; g[2 * a + 1] = box[2 * a + 1] + E; }
+    return aabb_hit_fused(g, r, tmin, tmax, enter);
+}
 static void sah_ray(const ray *r, float c_ref, int prim_ref) {
     float c = 1e30f; int p = -1; int flag = 0; float p_enter = 0;
     struct { int idx; float enter; } stack[64]; int sp = 0, maxsp = 0;
     const float inv_len = 1.0f / sqrtf(lensq(r->d));
     const float bd = g_beta * inv_len;
-    {   /* far-origin test, as guard_origin() in the kernel */
+    if (!g_dyn) {   /* far-origin test, as guard_origin() in the kernel */
         float dd = 0; for (int a = 0; a < 3; a++) dd += (r->o.e[a] - g_sc[a]) * (r->o.e[a] - g_sc[a]);
         if (dd > g_d0 * g_d0) {
             n_far++;
@@ -191,7 +205,7 @@ static void sah_ray(const ray *r, float c_ref, int prim_ref) {
         } else {
             float el, er; v_sah += 2; v_sah_pairs++;
             const float cl = c + g_beta * c, cr = cl; (void)bd;
-            const int hl = g_fused ? aabb_hit_fused(g_s[n->left].box, r, 0.001f, cl, &el) : aabb_hit_e(g_s[n->left].box, r, 0.001f, cl, &el), hr = g_fused ? aabb_hit_fused(g_s[n->right].box, r, 0.001f, cr, &er) : aabb_hit_e(g_s[n->right].box, r, 0.001f, cr, &er);
+            const int hl = box_test(g_s[n->left].box, r, 0.001f, cl, &el), hr = box_test(g_s[n->right].box, r, 0.001f, cr, &er);
             if (hl && hr) {
                 const int lf = el <= er;
                 if (sp >= g_levels) { flag = 1; n_overflow++; }
@@ -222,6 +236,8 @@ int main(int argc, char **argv) {
     if (argc > 5) g_beta = (float)atof(argv[5]);
     if (argc > 6) g_levels = atoi(argv[6]);
     if (getenv("FUSED")) g_fused = 1;
+    if (getenv("DYN")) { g_dyn = 1; g_fused = 1; }
+    if (getenv("GAMMA_ULPS")) g_gamma = (float)atof(getenv("GAMMA_ULPS")) * 5.9604645e-8f;
     rtp_host_scene *hs = rtp_host_scene_rtiow(12345u, half, 0, 0);
     rt_scene_desc sc; rtp_host_scene_desc(hs, &sc);
     rt_camera_data cam;
@@ -261,12 +277,14 @@ int main(int argc, char **argv) {
             for (int a = 0; a < 3; a++) { if (g_rbox[6 * i + 2 * a] < g_bs[2 * a]) g_bs[2 * a] = g_rbox[6 * i + 2 * a]; if (g_rbox[6 * i + 2 * a + 1] > g_bs[2 * a + 1]) g_bs[2 * a + 1] = g_rbox[6 * i + 2 * a + 1]; }
         }
         g_fark = g_gamma / (2 * rmin);
+        g_dynk = g_gamma / (2 * rmin) * 1.000001f;
         { float reach = sqrtf(0.08f * rmin * rmin / g_gamma); if (reach < 2 * g_rs) reach = 2 * g_rs; g_d0 = reach - g_rs; }
         if (argc > 7) g_d0 = (float)atof(argv[7]);
         for (int i = 0; i < sc.num_spheres; i++) {
             float dc = 0; for (int a = 0; a < 3; a++) dc += (sc.spheres[i].center.e[a] - g_sc[a]) * (sc.spheres[i].center.e[a] - g_sc[a]);
             const float reach = sc.spheres[i].radius < 100 ? g_d0 + g_rs : 1.25f * 2002.0f;
-            const float eps = g_gamma * reach * reach / (2 * sc.spheres[i].radius);
+            float eps = g_gamma * reach * reach / (2 * sc.spheres[i].radius);
+            if (g_dyn && sc.spheres[i].radius < 100) eps = 32 * 5.96e-8f * (2 * g_rs + 2002.0f);      /* the rounding floor only */
             for (int a = 0; a < 3; a++) { g_pbox[6 * i + 2 * a] -= eps; g_pbox[6 * i + 2 * a + 1] += eps; }
             if (i < 3 || i == sc.num_spheres - 1) printf("sphere %d r %.3g eps %.3g\n", i, sc.spheres[i].radius, eps);
         }
