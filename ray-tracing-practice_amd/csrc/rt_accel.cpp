@@ -695,6 +695,79 @@ void Packer::pair_tables() {
             out.hnodes[k * 8 + 7] = o[13];
         }
     }
+    // ---- 4-wide nodes (Guarded, host-built tree): the binary tree collapsed — an inner child is replaced by its own
+    // two children, largest box first, until the node has four children or only leaves.  Half the steps per ray for
+    // slightly FEWER box tests (tools/nearfirst_study.c WIDE=1: S-rtiow 5.4 steps / 20.1 box tests per ray instead of
+    // 10.8 / 22.6; S-100k 10.1 / 39.5 instead of 20.0 / 41.1).  Same boxes, same leaves: everything DESIGN.md §3b says
+    // about the guarded walk holds unchanged.  Nodes are numbered breadth-first (top of the tree first, for the LDS
+    // treelet of big scenes).
+    //   wnodes  (fp32, 7 x float4): lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] code[4]
+    //   whnodes (binary16 rounded outward, 4 x float4): 24 halves in the same order, then code[4]
+    //   unused child slots: code kTraversalDone (the kernel tells them by the code, not by the box).
+    if (mode == TreeMode::Guarded && out.root >= 0) {
+        struct Wide { int32_t child[4]; int n; };
+        std::vector<Wide> wide;
+        std::vector<int32_t> wide_of(bnodes.size(), -1), order;       // binary inner node → wide node; BFS queue of binary nodes
+        order.push_back(out.root);
+        wide_of[static_cast<size_t>(out.root)] = 0;
+        for (size_t head = 0; head < order.size(); ++head) {
+            const BuildNode &b = bnodes[static_cast<size_t>(order[head])];
+            Wide w{{b.child[0], b.child[1], kTraversalDone, kTraversalDone}, 2};
+            while (w.n < 4) {
+                int best = -1;
+                float best_area = -1.0f;
+                for (int k = 0; k < w.n; ++k)
+                    if (w.child[k] >= 0) {
+                        const float a = half_area(bnodes[static_cast<size_t>(w.child[k])].box);
+                        if (a > best_area) { best_area = a; best = k; }
+                    }
+                if (best < 0) break;
+                const BuildNode &c = bnodes[static_cast<size_t>(w.child[best])];
+                w.child[best] = c.child[0];
+                w.child[w.n++] = c.child[1];
+            }
+            for (int k = 0; k < w.n; ++k)
+                if (w.child[k] >= 0) {
+                    wide_of[static_cast<size_t>(w.child[k])] = static_cast<int32_t>(order.size());
+                    order.push_back(w.child[k]);
+                }
+            wide.push_back(w);
+        }
+        out.num_wide = static_cast<int32_t>(wide.size());
+        out.num_top_wide = std::min<int32_t>(out.num_wide, 1024);
+        out.wroot = 0;
+        out.wnodes.assign(wide.size() * 28, 0.0f);
+        out.whnodes.assign(wide.size() * 16, 0.0f);
+        for (size_t i = 0; i < wide.size(); ++i) {
+            float *o = &out.wnodes[i * 28];
+            uint16_t h[24];
+            for (int k = 0; k < 4; ++k) {
+                const int32_t code = wide[i].child[k];
+                const float *b = box_of(code);
+                for (int a = 0; a < 3; ++a) {
+                    o[(2 * a) * 4 + k] = b[2 * a];
+                    o[(2 * a + 1) * 4 + k] = b[2 * a + 1];
+                    h[(2 * a) * 4 + k] = float_to_half_dir(b[2 * a], true);
+                    h[(2 * a + 1) * 4 + k] = float_to_half_dir(b[2 * a + 1], false);
+                }
+                const int32_t mapped = code >= 0 ? wide_of[static_cast<size_t>(code)] : code;
+                o[24 + k] = bits_as_float(mapped);
+                out.whnodes[i * 16 + 12 + static_cast<size_t>(k)] = bits_as_float(mapped);
+            }
+            std::memcpy(&out.whnodes[i * 16], h, sizeof(h));       // 48 bytes = floats 0..11
+        }
+        // stack bound of the wide walk: up to three entries per level
+        int32_t maxd = 0;
+        std::function<void(int32_t, int32_t)> wwalk = [&](int32_t w, int32_t dep) {
+            maxd = std::max(maxd, dep);
+            for (int k = 0; k < wide[static_cast<size_t>(w)].n; ++k) {
+                const int32_t c = wide[static_cast<size_t>(w)].child[k];
+                if (c >= 0) wwalk(wide_of[static_cast<size_t>(c)], dep + 1);
+            }
+        };
+        wwalk(0, 1);
+        out.wide_depth = maxd;
+    }
     // depth of the traversal tree (stack bound: one entry per level at most)
     {
         int32_t maxd = 0;

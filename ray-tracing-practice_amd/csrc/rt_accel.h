@@ -49,6 +49,10 @@ struct Packed {
     int32_t num_internal = 0;
     int32_t num_top_pairs = 0;     // Guarded: nodes [0, num_top_pairs) are the top of the tree, breadth-first
     int32_t max_depth = 0;         // longest root→leaf path in internal nodes = traversal stack bound
+    // Guarded, host-built tree: the same tree collapsed to 4-wide nodes (layout in rt_accel.cpp); empty when the root is a leaf
+    std::vector<float> wnodes;     // 28 floats per wide node (fp32 boxes)
+    std::vector<float> whnodes;    // 16 floats per wide node (binary16 boxes rounded outward)
+    int32_t num_wide = 0, num_top_wide = 0, wroot = kTraversalDone, wide_depth = 0;
     // Guarded near-first walk (TreeMode::Guarded): `nodes` then is an SAH tree over
     // leaf boxes INFLATED by a per-sphere margin, and the kernel sends every sample whose result
     // could depend on the visit order to the exact reference-order walk.  guard.ok == false (with

@@ -78,6 +78,7 @@ void config_defaults(rt_config &c) {
     c.scene_in_lds = 1;
     c.lds_treelet = 1;
     c.reserve_taper = 1;
+    c.wide_nodes = 0;
 }
 
 // A caller compiled against an older, shorter rt_config: its fields, defaults for the rest.
@@ -113,6 +114,8 @@ struct rt_scene {
     float4 *tnodes = nullptr, *xnodes = nullptr;
     int32_t num_tnodes = 0, num_top = 0, num_top_pairs = 0;
     float4 *hnodes = nullptr;       // pair records with binary16 planes (guarded walk from global memory)
+    float4 *wnodes = nullptr, *whnodes = nullptr;     // the same tree as 4-wide nodes (fp32 / binary16 boxes); null: pair nodes only
+    int32_t num_wide = 0, num_top_wide = 0, wroot = rtk::kDone, wide_depth = 0;
     float4 *nodes = nullptr, *spheres = nullptr, *planes = nullptr, *materials = nullptr, *tex_data = nullptr;
     int32_t *sphere_mat = nullptr;
     int4 *tex_info = nullptr;
@@ -214,6 +217,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.part = s.part;
     P.local_rows = rt_shard_rows(cam->image_height, shard);
     P.nodes = sc->nodes; P.hnodes = sc->hnodes; P.num_internal = sc->num_internal; P.root = sc->root;
+    P.wnodes = sc->wnodes; P.whnodes = sc->whnodes; P.num_wide = sc->num_wide; P.wroot = sc->wroot;
     P.tnodes = sc->tnodes; P.num_tnodes = sc->num_tnodes;
     P.xnodes = sc->xnodes; P.num_top = sc->num_top;
     P.spheres = sc->spheres; P.num_spheres = sc->num_spheres;
@@ -269,15 +273,18 @@ rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream
         return RT_OK;
     }
     HIP_TRY(hipStreamSynchronize(stream));          // the old tables may still be in use on this stream
-    float4 *nodes = nullptr, *hnodes = nullptr, *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;
+    float4 *nodes = nullptr, *hnodes = nullptr, *wnodes = nullptr, *whnodes = nullptr, *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;
     rt_status st = RT_OK;
     if ((st = upload(pk.nodes, (void **)&nodes)) != RT_OK || (st = upload(pk.hnodes, (void **)&hnodes)) != RT_OK ||
+        (st = upload(pk.wnodes, (void **)&wnodes)) != RT_OK || (st = upload(pk.whnodes, (void **)&whnodes)) != RT_OK ||
         (st = upload(pk.leaf_boxes, (void **)&leaf_boxes)) != RT_OK || (st = upload(pk.plane_leaf_boxes, (void **)&plane_leaf_boxes)) != RT_OK) {
-        (void)hipFree(nodes); (void)hipFree(hnodes); (void)hipFree(leaf_boxes); (void)hipFree(plane_leaf_boxes);
+        (void)hipFree(nodes); (void)hipFree(hnodes); (void)hipFree(wnodes); (void)hipFree(whnodes); (void)hipFree(leaf_boxes); (void)hipFree(plane_leaf_boxes);
         return st;
     }
-    (void)hipFree(sc->nodes); (void)hipFree(sc->hnodes); (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes);
-    sc->nodes = nodes; sc->hnodes = hnodes; sc->leaf_boxes = leaf_boxes; sc->plane_leaf_boxes = plane_leaf_boxes;
+    (void)hipFree(sc->nodes); (void)hipFree(sc->hnodes); (void)hipFree(sc->wnodes); (void)hipFree(sc->whnodes);
+    (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes);
+    sc->nodes = nodes; sc->hnodes = hnodes; sc->wnodes = wnodes; sc->whnodes = whnodes; sc->leaf_boxes = leaf_boxes; sc->plane_leaf_boxes = plane_leaf_boxes;
+    sc->num_wide = pk.num_wide; sc->num_top_wide = pk.num_top_wide; sc->wroot = pk.wroot; sc->wide_depth = pk.wide_depth;
     sc->num_internal = pk.num_internal;
     sc->num_top_pairs = pk.num_top_pairs;
     sc->root = pk.root;
@@ -337,6 +344,7 @@ void rt_config_from_env(rt_config *cfg) {
     cfg->wavefront_paths = env_int("RTP_WF_PATHS", cfg->wavefront_paths);
     cfg->wavefront_exchange = env_int("RTP_WF_EXCHANGE", cfg->wavefront_exchange);
     if (env_int("RTP_NO_TAPER", 0)) cfg->reserve_taper = 0;
+    cfg->wide_nodes = env_int("RTP_WIDE", cfg->wide_nodes);
 }
 
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) { return rt_scene_create_ex(desc, nullptr, out_scene); }
@@ -401,6 +409,9 @@ rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cf
     } else {
         if ((st = upload(pk.nodes, (void **)&sc->nodes)) != RT_OK) return bail(st);
         if ((st = upload(pk.hnodes, (void **)&sc->hnodes)) != RT_OK) return bail(st);
+        if ((st = upload(pk.wnodes, (void **)&sc->wnodes)) != RT_OK) return bail(st);
+        if ((st = upload(pk.whnodes, (void **)&sc->whnodes)) != RT_OK) return bail(st);
+        sc->num_wide = pk.num_wide; sc->num_top_wide = pk.num_top_wide; sc->wroot = pk.wroot; sc->wide_depth = pk.wide_depth;
     }
     if ((st = upload(pk.tnodes, (void **)&sc->tnodes)) != RT_OK) return bail(st);
     sc->num_tnodes = pk.num_tnodes;
@@ -439,7 +450,8 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     if (!sc) return RT_OK;
     (void)hipFree(sc->tnodes);
     (void)hipFree(sc->xnodes);
-    (void)hipFree(sc->nodes); (void)hipFree(sc->hnodes); (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
+    (void)hipFree(sc->nodes); (void)hipFree(sc->hnodes); (void)hipFree(sc->wnodes); (void)hipFree(sc->whnodes);
+    (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
     (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list); (void)hipFree(sc->wf_pool);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
@@ -518,6 +530,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     Shape fast{};
     // kernel form of the guarded pass: render_kernel (a lane owns a path) or render_kernel_wf (a wave owns a pool of paths)
     const bool want_wavefront = cfg.kernel == RT_KERNEL_WAVEFRONT;
+    // 4-wide nodes where the scene has them (host-built tree with at least one inner node) and the configuration does not
+    // ask for the pair nodes; the wavefront kernel walks pairs
+    const bool wide = sc->wnodes != nullptr && sc->num_wide > 0 && cfg.wide_nodes != 0 && !want_wavefront;
     const uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
     const int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
     if (guarded) {
@@ -542,8 +557,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (sc->repack_refused && sc->guard.num_small > 0 && outside(sc->guard.center, (double)sc->guard.d0_sq)) guarded = false;
     }
     if (guarded) {
-        const uint64_t table_bytes = ((uint64_t)P.num_internal * 4 + prim_f4) * 16;      // fp32 pair records when LDS-resident
-        const int32_t want = sc->tree_depth + 1 > 2 ? sc->tree_depth + 1 : 2;       // never overflows
+        const uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * 4) + prim_f4) * 16;      // fp32 records when LDS-resident
+        const int32_t deepest = wide ? 3 * sc->wide_depth : sc->tree_depth;          // a wide node leaves up to three children waiting
+        const int32_t want = deepest + 1 > 2 ? deepest + 1 : 2;       // never overflows
         const uint32_t per_level = gblock * 4u;
         // tables in LDS when they leave room for a useful stack at full occupancy; else they are read
         // through L1/L2 and LDS holds only the stacks
@@ -573,10 +589,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (!fast.in_lds && cfg.lds_treelet) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level;
-            const int64_t fit = budget > used ? (int64_t)((budget - used) / 32) : 0;
-            fast.num_top = (int32_t)(fit < sc->num_top_pairs ? fit : sc->num_top_pairs);
+            const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;
+            const int32_t top_have = wide ? sc->num_top_wide : sc->num_top_pairs;
+            fast.num_top = (int32_t)(fit < top_have ? fit : top_have);
         }
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * 32) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32)) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
     }
     bool use_queue = false;
@@ -777,6 +794,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
                 P.wf_k_exchange = cfg.wavefront_exchange > 0 ? (cfg.wavefront_exchange > 64 ? 64 : cfg.wavefront_exchange) : 16;
                 if (fast.in_lds) HIP_TRY(launch_wf(rtk::render_kernel_wf<true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch_wf(rtk::render_kernel_wf<false>, P, wgs, fast.lds_bytes));
+            } else if (wide) {
+                if (dyn) {
+                    if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true, true>, P, wgs, fast.lds_bytes));
+                    else HIP_TRY(launch(rtk::render_kernel<false, false, true, true>, P, wgs, fast.lds_bytes));
+                } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
+                else HIP_TRY(launch(rtk::render_kernel<false, false, false, true>, P, wgs, fast.lds_bytes));
             } else if (dyn) {
                 if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true>, P, wgs, fast.lds_bytes));
@@ -821,6 +844,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last.guard_unproven = (guarded && gamma_unproven(cfg)) ? 1u : 0u;
     sc->last.kernel = wavefront ? RT_KERNEL_WAVEFRONT : RT_KERNEL_MEGA;
     sc->last.guard_dynamic = dyn ? 1u : 0u;
+    sc->last.wide_nodes = (guarded && wide) ? 1u : 0u;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);

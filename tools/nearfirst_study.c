@@ -34,6 +34,7 @@ static inline int aabb_hit_e(const float box[6], const ray *r, float tmin, float
 }
 
 struct snode_s; static void *g_s_any; static void sah_ray(const ray *r, float c_ref, int prim_ref);
+static void *g_w_any; static void wide_ray(const ray *r, float c_ref, int prim_ref);
 static int g_fused = 0;
 static inline int aabb_hit_fused(const float box[6], const ray *r, float tmin0, float tmax0, float *enter) {
     float nr[3], fr[3];
@@ -103,6 +104,7 @@ static void study_ray(const void *scv, const void *rv) {
         }
     }
     if (g_s_any) sah_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
+    if (g_w_any) wide_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     const int flagged = flagged_prune | flagged_incons;
     n_flag += flagged; n_flag_prune += flagged_prune; n_flag_incons += flagged_incons;
     const int mismatch = (p != p_ref) || (p >= 0 && c != c_ref);
@@ -224,6 +226,51 @@ static void sah_ray(const ray *r, float c_ref, int prim_ref) {
     const int mm = (p != prim_ref) || (p >= 0 && c != c_ref);
     n_sah_mismatch += mm; if (mm && !flag) { n_sah_mismatch_unflagged++; fprintf(stderr, "UNFLAGGED MISMATCH: ref prim %d t %.9g  got prim %d t %.9g  o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", prim_ref, c_ref, p, c, r->o.e[0], r->o.e[1], r->o.e[2], r->d.e[0], r->d.e[1], r->d.e[2]); }
 }
+/* ---- WIDE=1: the same tree collapsed to 4-wide nodes (a child that is an inner node is replaced by its two children,
+ * largest box first, until the node has four children or only leaves); near-first walk: all children tested in one
+ * step, the nearest hit child is entered, the others are pushed far-to-near. */
+typedef struct { int child[4]; int n; } wnode;      /* child: index into g_s (leaf iff g_s[c].left < 0) */
+static wnode *g_w; static int *g_wof;               /* g_wof[binary inner node] = its wide node */
+static unsigned long long w_steps, w_boxes, w_leaf, w_mismatch, w_push, w_maxsp_hist[64];
+static void wide_build(int i) {
+    wnode *w = &g_w[i];
+    w->n = 2; w->child[0] = g_s[i].left; w->child[1] = g_s[i].right;
+    for (;;) {
+        if (w->n == 4) break;
+        int best = -1; float ba = -1;
+        for (int k = 0; k < w->n; k++) if (g_s[w->child[k]].left >= 0) { const float a = area(g_s[w->child[k]].box); if (a > ba) { ba = a; best = k; } }
+        if (best < 0) break;
+        const int c = w->child[best];
+        w->child[best] = g_s[c].left; w->child[w->n++] = g_s[c].right;
+    }
+    for (int k = 0; k < w->n; k++) if (g_s[w->child[k]].left >= 0) wide_build(w->child[k]);
+}
+static void wide_ray(const ray *r, float c_ref, int prim_ref) {
+    float c = 1e30f; int p = -1;
+    struct { int idx; float enter; } stack[128]; int sp = 0, maxsp = 0;
+    int cur = 0; float e0;
+    if (!box_test(g_s[0].box, r, 0.001f, 1e30f, &e0)) cur = -1;
+    while (cur >= 0) {
+        if (g_s[cur].left < 0) {
+            hitrec tmp; w_leaf++;
+            if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[g_s[cur].prim])) { c = tmp.t; p = g_s[cur].prim; }
+        } else {
+            const wnode *w = &g_w[cur];
+            w_steps++; w_boxes += w->n;
+            int hi[4]; float he[4]; int nh = 0;
+            const float cl = c + g_beta * c;
+            for (int k = 0; k < w->n; k++) { float e; if (box_test(g_s[w->child[k]].box, r, 0.001f, cl, &e)) { hi[nh] = w->child[k]; he[nh++] = e; } }
+            for (int a = 1; a < nh; a++) for (int b = a; b > 0 && he[b] < he[b - 1]; b--) { const float te = he[b]; he[b] = he[b - 1]; he[b - 1] = te; const int ti = hi[b]; hi[b] = hi[b - 1]; hi[b - 1] = ti; }
+            for (int k = nh - 1; k >= 1; k--) { stack[sp].idx = hi[k]; stack[sp++].enter = he[k]; w_push++; }
+            if (sp > maxsp) maxsp = sp;
+            if (nh > 0) { cur = hi[0]; continue; }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp].idx;
+    }
+    w_maxsp_hist[maxsp < 63 ? maxsp : 63]++;
+    if ((p != prim_ref) || (p >= 0 && c != c_ref)) w_mismatch++;
+}
 static float fill_rmax(int i) {
     if (g_s[i].left < 0) return g_rmax[i] = g_scn->spheres[g_s[i].prim].radius;
     const float a = fill_rmax(g_s[i].left), b = fill_rmax(g_s[i].right);
@@ -293,6 +340,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < sc.num_spheres; i++) ids[i] = i;
     snode *sn = malloc(sizeof(snode) * 2 * sc.num_spheres);
     g_s = sn; g_sn = 0; sah_build(ids, sc.num_spheres); g_rmax = malloc(sizeof(float) * g_sn); fill_rmax(0); g_s_any = sn;
+    if (getenv("WIDE")) { g_w = calloc(g_sn, sizeof(wnode)); wide_build(0); g_w_any = g_w; }
     float *fb = malloc((size_t)W * H * 3 * sizeof(float));
     orc_render(&sc, &cam, 0, H, fb, 1, NULL);
     printf("scene half=%d nodes=%d  %dx%d spp=%d delta=%g\n", half, sc.num_nodes, W, H, spp, g_delta);
@@ -304,6 +352,12 @@ int main(int argc, char **argv) {
            (double)v_sah / n_rays, (double)v_sah_pairs / n_rays, (double)lt_sah / n_rays);
     printf("  flagged %.4f%% (ties %llu, inconsistent final %llu, overflow %llu)  mismatches %llu (unflagged %llu)  far origins %llu (flagged %llu)  max departure/eps %.3g\n",
            100.0 * n_sah_flag / n_rays, n_tie, n_incons_final, n_overflow, n_sah_mismatch, n_sah_mismatch_unflagged, n_far, n_far_flag, g_max_ratio);
+    if (g_w) {
+        printf("WIDE (4-wide collapse): steps/ray %.2f  box tests/ray %.2f  leaf tests/ray %.2f  pushes/ray %.2f  mismatches (unguarded) %llu  max stack:", (double)w_steps / n_rays,
+               (double)w_boxes / n_rays, (double)w_leaf / n_rays, (double)w_push / n_rays, w_mismatch);
+        for (int i = 0; i < 64; i++) if (w_maxsp_hist[i]) printf(" %d:%.3f%%", i, 100.0 * w_maxsp_hist[i] / n_rays);
+        printf("\n");
+    }
     printf("  max pending-stack depth per ray:");
     for (int i = 0; i < 24; i++) if (depth_hist[i]) printf(" %d:%.4f%%", i, 100.0 * depth_hist[i] / n_rays);
     printf("\n");
