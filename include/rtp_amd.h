@@ -175,7 +175,9 @@ typedef struct rt_config {
     int32_t  guard_keep;          /* 1: keep the guarded walk even after a frame that flagged > 2 % of its samples */
     int32_t  guard_repack;        /* 1 (default): re-pack the guarded tree for a camera outside the reach it was sized for */
     int32_t  kernel;              /* RT_KERNEL_*: AUTO picks per scene */
-    uint64_t workspace_bytes;     /* budget of the per-pass sample workspace the scene handle owns (0 = default) */
+    uint64_t workspace_bytes;     /* budget of the per-pass sample workspace the scene handle owns (12 bytes per sample of a
+                                     pass, allocated on demand).  0 = default: a sixteenth of the device's memory.  A smaller
+                                     budget means more, shorter passes: 4 GiB costs 1.9 % at 1920x1080x500 spp */
     int32_t  pass_spp;            /* samples per pixel per pass (0 = auto: what the workspace admits) */
     int32_t  stack_levels;        /* cap on the guarded walk's per-lane stack entries (0 = auto) */
     uint32_t flag_capacity;       /* cap on the flagged-sample list (0 = auto; overflow = "re-walk everything") */

@@ -42,7 +42,11 @@ int env_int(const char *name, int fallback) {
     return (v && *v) ? atoi(v) : fallback;
 }
 
-constexpr uint64_t kDefaultWorkspaceBytes = ((uint64_t)4 << 30) - ((uint64_t)64 << 20);      // just under 4 GiB
+// rt_config.workspace_bytes == 0: a sixteenth of the device's memory (18 GB of an MI355X's 288 GB).  The sample slab of a
+// pass is the only large allocation of a scene handle and is grown on demand to what the frames actually need: 12.4 GB for
+// one 1920x1080x500-spp pass.  A smaller budget only cuts the frame into more passes: 4 GiB → 3 passes, 1.9 % slower
+// (each extra pass costs the drain of a trace launch and one more re-walk launch, ≈1.7 ms).
+constexpr uint64_t kWorkspaceShareOfDevice = 16;
 constexpr uint64_t kSampleBytes = 12;        // one radiance record of the slab
 
 constexpr uint32_t kLdsLimit = 160 * 1024;
@@ -74,7 +78,7 @@ void config_defaults(rt_config &c) {
     c.guard_min_primitives = 16;
     c.guard_repack = 1;
     c.kernel = RT_KERNEL_AUTO;
-    c.workspace_bytes = kDefaultWorkspaceBytes;
+    c.workspace_bytes = 0;
     c.scene_in_lds = 1;
     c.lds_treelet = 1;
     c.reserve_taper = 1;
@@ -90,7 +94,6 @@ rt_config config_from_caller(const rt_config *in) {
         std::memcpy(&c, in, n);
         c.struct_bytes = (uint32_t)sizeof(rt_config);
     }
-    if (c.workspace_bytes == 0) c.workspace_bytes = kDefaultWorkspaceBytes;
     if (c.guard_min_primitives < 0) c.guard_min_primitives = 0;
     return c;
 }
@@ -146,6 +149,7 @@ struct rt_scene {
     uint64_t last_samples = 0;
     bool timed = false;
     int num_cus = 0;
+    uint64_t device_bytes = 0;      // total memory of the device (workspace default: a sixteenth of it)
     float build_ms = 0.0f;          // device BVH build time (RTP_BUILD=device), else 0
 };
 
@@ -395,6 +399,7 @@ rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cf
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, sc->device) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
     sc->num_cus = prop.multiProcessorCount;
+    sc->device_bytes = (uint64_t)prop.totalGlobalMem;
     if (device_build && pk.guard.ok) {
         rtbuild::DeviceTree tree;
         const std::string berr = rtbuild::build_lbvh(pk.guard_leaf_boxes.data(), pk.guard_leaf_codes.data(), (int32_t)pk.guard_leaf_codes.size(), tree);
@@ -611,7 +616,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     int pass_size = P.spp;
     auto pitch_of = [](int pass) { return (uint32_t)((pass + 3) & ~3); };       // rows of the slab are 16-byte aligned
     {
-        const uint64_t budget = cfg.workspace_bytes;
+        const uint64_t budget = cfg.workspace_bytes ? cfg.workspace_bytes : sc->device_bytes / kWorkspaceShareOfDevice;
         uint64_t fit = budget / ((uint64_t)num_pixels * kSampleBytes);
         fit &= ~(uint64_t)3;
         const uint64_t index_fit = (((uint64_t)1 << 30) - 64) / num_pixels;     // total_work + 64 <= 2^30
