@@ -35,6 +35,7 @@ static inline int aabb_hit_e(const float box[6], const ray *r, float tmin, float
 
 struct snode_s; static void *g_s_any; static void sah_ray(const ray *r, float c_ref, int prim_ref);
 static void *g_w_any; static void wide_ray(const ray *r, float c_ref, int prim_ref);
+static int g_defer_on; static void defer_ray(const ray *r, float c_ref, int prim_ref);
 static int g_fused = 0;
 static inline int aabb_hit_fused(const float box[6], const ray *r, float tmin0, float tmax0, float *enter) {
     float nr[3], fr[3];
@@ -105,6 +106,7 @@ static void study_ray(const void *scv, const void *rv) {
     }
     if (g_s_any) sah_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     if (g_w_any) wide_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
+    if (g_defer_on) defer_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     const int flagged = flagged_prune | flagged_incons;
     n_flag += flagged; n_flag_prune += flagged_prune; n_flag_incons += flagged_incons;
     const int mismatch = (p != p_ref) || (p >= 0 && c != c_ref);
@@ -271,6 +273,41 @@ static void wide_ray(const ray *r, float c_ref, int prim_ref) {
     w_maxsp_hist[maxsp < 63 ? maxsp : 63]++;
     if ((p != prim_ref) || (p >= 0 && c != c_ref)) w_mismatch++;
 }
+/* ---- DEFER=k: the guarded walk with a one-entry "pending primitive": a lane that reaches a leaf does not stop for the
+ * primitive test, it parks the leaf and walks on; the parked leaf is tested when a second leaf is reached, after k more
+ * pair steps (the wave's next leaf step), or at the end.  Counts the extra box tests the later pruning costs. */
+static int g_defer = 0;
+static unsigned long long df_pairs, df_leaf, df_mismatch;
+static void defer_ray(const ray *r, float c_ref, int prim_ref) {
+    float c = 1e30f; int p = -1;
+    int stack[128]; int sp = 0;
+    int pend = -1, pend_age = 0;
+    int cur = 0; float e0;
+    if (!box_test(g_s[0].box, r, 0.001f, 1e30f, &e0)) cur = -1;
+    int done = cur < 0;
+    for (;;) {
+        if (pend >= 0 && (pend_age >= g_defer || done || g_s[cur].left < 0)) {      /* test the parked leaf */
+            hitrec tmp; df_leaf++;
+            if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[g_s[pend].prim])) { c = tmp.t; p = g_s[pend].prim; }
+            pend = -1;
+        }
+        if (done) break;
+        const snode *n = &g_s[cur];
+        int next = -1;
+        if (n->left < 0) { pend = cur; pend_age = 0; }
+        else {
+            float el, er; df_pairs++; pend_age++;
+            const float cl = c + g_beta * c;
+            const int hl = box_test(g_s[n->left].box, r, 0.001f, cl, &el), hr = box_test(g_s[n->right].box, r, 0.001f, cl, &er);
+            if (hl && hr) { const int lf = el <= er; stack[sp++] = lf ? n->right : n->left; next = lf ? n->left : n->right; }
+            else if (hl) next = n->left;
+            else if (hr) next = n->right;
+        }
+        if (next < 0) { if (sp == 0) done = 1; else next = stack[--sp]; }
+        cur = next;
+    }
+    if ((p != prim_ref) || (p >= 0 && c != c_ref)) df_mismatch++;
+}
 static float fill_rmax(int i) {
     if (g_s[i].left < 0) return g_rmax[i] = g_scn->spheres[g_s[i].prim].radius;
     const float a = fill_rmax(g_s[i].left), b = fill_rmax(g_s[i].right);
@@ -340,6 +377,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < sc.num_spheres; i++) ids[i] = i;
     snode *sn = malloc(sizeof(snode) * 2 * sc.num_spheres);
     g_s = sn; g_sn = 0; sah_build(ids, sc.num_spheres); g_rmax = malloc(sizeof(float) * g_sn); fill_rmax(0); g_s_any = sn;
+    if (getenv("DEFER")) { g_defer = atoi(getenv("DEFER")); g_defer_on = 1; }
     if (getenv("WIDE")) { g_w = calloc(g_sn, sizeof(wnode)); wide_build(0); g_w_any = g_w; }
     float *fb = malloc((size_t)W * H * 3 * sizeof(float));
     orc_render(&sc, &cam, 0, H, fb, 1, NULL);
@@ -358,6 +396,8 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 64; i++) if (w_maxsp_hist[i]) printf(" %d:%.3f%%", i, 100.0 * w_maxsp_hist[i] / n_rays);
         printf("\n");
     }
+    if (g_defer_on) printf("DEFER (parked leaf, tested after %d pair steps): pair steps/ray %.2f  leaf tests/ray %.2f  mismatches (unguarded) %llu\n", g_defer,
+                           (double)df_pairs / n_rays, (double)df_leaf / n_rays, df_mismatch);
     printf("  max pending-stack depth per ray:");
     for (int i = 0; i < 24; i++) if (depth_hist[i]) printf(" %d:%.4f%%", i, 100.0 * depth_hist[i] / n_rays);
     printf("\n");
