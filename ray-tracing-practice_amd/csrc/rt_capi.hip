@@ -614,11 +614,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     // the pass grows N-fold, so a launch keeps the size it has on one GPU.
     const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
     int pass_size = P.spp;
-    auto pitch_of = [](int pass) { return (uint32_t)((pass + 3) & ~3); };       // rows of the slab are 16-byte aligned
+    auto pitch_of = [](int pass) { return (uint32_t)((pass + 31) & ~31); };     // rows of the slab start on 128-byte lines (32 x 12 B = 3 lines)
     {
         const uint64_t budget = cfg.workspace_bytes ? cfg.workspace_bytes : sc->device_bytes / kWorkspaceShareOfDevice;
         uint64_t fit = budget / ((uint64_t)num_pixels * kSampleBytes);
-        fit &= ~(uint64_t)3;
+        fit &= ~(uint64_t)31;
         const uint64_t index_fit = (((uint64_t)1 << 30) - 64) / num_pixels;     // total_work + 64 <= 2^30
         if (fit > index_fit) fit = index_fit;
         if (fit < 64) fit = 64;
@@ -829,7 +829,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             sc->timed_passes = pass + 1;
         }
         // … then added to the pixel sums strictly in sample order
-        hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 255) / 256), dim3(256), 0, stream, d_fb_sum,
+        hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 64 * rtk::kAccWaves - 1) / (64 * rtk::kAccWaves)), dim3(64 * rtk::kAccWaves), 0, stream, d_fb_sum,
                            (const float *)sc->slab, num_pixels, P.slab_pitch, P.pass_count, pass == 0 ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
