@@ -155,7 +155,6 @@ def _fold_pmc(out, args):
             "wave_time_split": {"issuing": round(valu["SQ_ACTIVE_INST_ANY"] / valu["SQ_WAVE_CYCLES"], 3),
                                 "s_waitcnt": round(valu["SQ_WAIT_ANY"] / valu["SQ_WAVE_CYCLES"], 3),
                                 "issue_stalled": round(valu["SQ_WAIT_INST_ANY"] / valu["SQ_WAVE_CYCLES"], 3)},
-            "profiled_clock_ghz": None,
             "source": "rocprofv3 --pmc passes run by this bench invocation (one frame each, counters only)",
             "formula": "frac = issue x lanes; issue = 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8); lanes = "
                        "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
