@@ -19,3 +19,22 @@ def test_accel_tables_under_sanitizers(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all ok" in out.stdout
+
+
+def test_margin_budget_against_adversarial_rays(tmp_path):
+    """The error budget behind the guarded walk's margins (gamma = 24 ulp of |oc|^2 |d|^2 in hit_sphere's discriminant,
+    DESIGN.md §3b): 400 k rays aimed at and around the silhouettes of tiny spheres from up to 2 000 units away — where
+    hb^2 - a*c cancels — through the oracle's hit_sphere; every computed hit, true or phantom (a quarter of them are
+    phantom hits of rays that miss), must lie within gamma |oc|^2 / (2 r) of the surface.  The largest budget these rays
+    actually use is just under 8 ulp — which is why 8 (round 1's margin for big scenes) is not a bound and 24 is."""
+    import re
+    exe = str(tmp_path / "margin_bound")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-std=gnu11", "-w", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpu_native", "test_margin_bound.c"), "-lm", "-lpthread"], check=True)
+    out = subprocess.run([exe, "400000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"computed hits (\d+)\s+phantom hits (\d+)\s+largest budget used ([0-9.]+) ulp", out.stdout)
+    assert m, out.stdout
+    hits, phantom, used = int(m.group(1)), int(m.group(2)), float(m.group(3))
+    assert hits > 200000 and phantom > 10000          # the cancellation cases are really being produced
+    assert 4.0 < used < 24.0
