@@ -521,7 +521,14 @@ void Packer::prepare_guard() {
                 // dyn_k * (distance from the ray's own origin to the box's farthest corner)^2, which bounds
                 // gamma |o - c_q|^2 / (2 r_q) for every small sphere q below the box, wherever the ray starts.
                 const double eps_static = gamma * reach * reach / (2.0 * r_min_small);
-                const bool dynamic = opt.dynamic == 2 || (opt.dynamic == 0 && eps_static > 0.25 * r_min_small);
+                // … automatically only where the small spheres are of one size class (largest / smallest radius <= 8): the
+                // growth factor dyn_k follows the SMALLEST of them, so with radii spread over decades every box of the tree
+                // would grow for the sake of a few specks and the walk loses to the reference's (tools/guard_stress.py:
+                // 2-3 x slower on such scenes); those keep the static rule, i.e. mostly the exact walk
+                double r_max_small = 0;
+                for (int i = 0; i < d.num_spheres; ++i)
+                    if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)]) r_max_small = std::max(r_max_small, double(d.spheres[i].radius));
+                const bool dynamic = opt.dynamic == 2 || (opt.dynamic == 0 && eps_static > 0.25 * r_min_small && r_max_small <= 8.0 * r_min_small);
                 if (!dynamic && eps_static > 64.0 * r_min_small) why = "margins exceed 64 radii for the smallest spheres";
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)

@@ -422,7 +422,8 @@ def test_context_renders_sharded_frames_through_the_c_abi():
 def test_distance_aware_margins():
     """rt_config.guard_dynamic_margins: (a) forced on S-rtiow (LDS-resident tables: render_kernel<true,false,true>), near
     and very far cameras — no far-origin flags, no re-pack needed; (b) tiny spheres scattered over a wide volume, a
-    scene whose static margins would exceed 64 radii (not eligible for the guarded walk before) now walks guarded;
+    scene whose static margins would exceed 64 radii: eligible for the guarded walk only with distance-aware margins,
+    which the automatic rule grants to scenes whose small spheres are of one size class (this one is not: forced here);
     frames are the oracle's."""
     host = rb.HostScene.rtiow()
     dev = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=2)
@@ -441,7 +442,9 @@ def test_distance_aware_margins():
     host = rb.HostScene.from_arrays(spheres, np.zeros((0, 11), np.float32), mats)
     static = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=1)
     assert "margins exceed" in static.guard_reason()
-    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    auto = rb.DeviceScene(host, device=0, honour_env=False)
+    assert "margins exceed" in auto.guard_reason()     # radii over a factor 30: the automatic rule keeps such scenes on the exact walk
+    dev = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=2)
     assert dev.guard_reason() == ""
     cam = rb.make_camera(320, 180, 50.0, (300, -250, 120), (0, 0, 0), (0.6, 0.7, 0.9), 4, 30)
     fb, t = dev.render_to_host(cam)
