@@ -1,6 +1,6 @@
 """BASELINE configs[4]: ~100k spheres + textured quad, 3840x2160, 1000 spp, depth 50 — one frame."""
 import os, sys, time
-sys.path.insert(0,'tests'); sys.path.insert(0,'ray-tracing-practice_amd')
+_R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,os.path.join(_R,'tests')); sys.path.insert(0,os.path.join(_R,'ray-tracing-practice_amd'))
 import rtp_bindings as rb, numpy as np, oracle_bindings as ob
 import torch
 spp=int(os.environ.get('SPP',1000))
