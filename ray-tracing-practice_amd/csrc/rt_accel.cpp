@@ -816,6 +816,9 @@ std::string Packer::primitive_tables() {
         const int32_t tag = m.type | (static_cast<int32_t>(m.texture_id) << 2);
         o[0] = m.albedo.e[0]; o[1] = m.albedo.e[1]; o[2] = m.albedo.e[2]; o[3] = bits_as_float(tag);
         o[4] = m.emit.e[0]; o[5] = m.emit.e[1]; o[6] = m.emit.e[2]; o[7] = m.fuzz;
+        // DIELECTRIC never reads fuzz: its slot carries the refraction ratio of a front-face hit, (float)(1.0 / ir)
+        // (include/materials.h:100), so the kernel's glass branch has one division less
+        if (m.type == RT_MAT_DIELECTRIC) o[7] = static_cast<float>(1.0 / static_cast<double>(m.ir));
         o[8] = m.absorption.e[0]; o[9] = m.absorption.e[1]; o[10] = m.absorption.e[2]; o[11] = m.ir;
     }
     size_t texels = 0;

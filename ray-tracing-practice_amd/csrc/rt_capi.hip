@@ -506,7 +506,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
 
     const uint32_t waves = rtk::kBlock / rtk::kWave;
     const uint32_t pool_bytes = waves * 8u;                  // per-wave reserved work range
-    const uint64_t prim_f4 = (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * 2 +      // LDS keeps 2 of the 3 material rows
+    const uint64_t prim_f4 = (uint64_t)P.num_spheres + (uint64_t)P.num_planes * 5 + (uint64_t)P.num_materials * RTP_LDS_MAT_ROWS +      // LDS keeps the first RTP_LDS_MAT_ROWS of the 3 material rows
                              ((uint64_t)P.num_spheres + 3) / 4;
 
     // ---- exact (threaded) walk: launch shape
@@ -562,7 +562,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (sc->repack_refused && sc->guard.num_small > 0 && outside(sc->guard.center, (double)sc->guard.d0_sq)) guarded = false;
     }
     if (guarded) {
-        const uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * 4) + prim_f4) * 16;      // fp32 records when LDS-resident
+        // fp32 records when LDS-resident: 7 float4 per wide node, 4 per pair node — 5 in the octant layout the kernel stages
+        // for the pair walk with static margins (rt_kernel.hip.inc, step_octant)
+        const bool octant = (RTP_OCTANT != 0) && !wide && !want_wavefront && !(sc->guard.dyn_k > 0.0f);
+        const uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * (octant ? 5 : 4)) + prim_f4) * 16;
         const int32_t deepest = wide ? 3 * sc->wide_depth : sc->tree_depth;          // a wide node leaves up to three children waiting
         const int32_t want = deepest + 1 > 2 ? deepest + 1 : 2;       // never overflows
         const uint32_t per_level = gblock * 4u;

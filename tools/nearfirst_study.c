@@ -36,6 +36,7 @@ static inline int aabb_hit_e(const float box[6], const ray *r, float tmin, float
 struct snode_s; static void *g_s_any; static void sah_ray(const ray *r, float c_ref, int prim_ref);
 static void *g_w_any; static void wide_ray(const ray *r, float c_ref, int prim_ref);
 static int g_defer_on; static void defer_ray(const ray *r, float c_ref, int prim_ref);
+static int g_leafk_on; static void leafk_ray(const ray *r, float c_ref, int prim_ref);
 static int g_fused = 0;
 static inline int aabb_hit_fused(const float box[6], const ray *r, float tmin0, float tmax0, float *enter) {
     float nr[3], fr[3];
@@ -107,6 +108,7 @@ static void study_ray(const void *scv, const void *rv) {
     if (g_s_any) sah_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     if (g_w_any) wide_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     if (g_defer_on) defer_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
+    if (g_leafk_on) leafk_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     const int flagged = flagged_prune | flagged_incons;
     n_flag += flagged; n_flag_prune += flagged_prune; n_flag_incons += flagged_incons;
     const int mismatch = (p != p_ref) || (p >= 0 && c != c_ref);
@@ -308,6 +310,69 @@ static void defer_ray(const ray *r, float c_ref, int prim_ref) {
     }
     if ((p != prim_ref) || (p >= 0 && c != c_ref)) df_mismatch++;
 }
+
+/* ---- LEAFK=k: leaves of up to k spheres (no per-sphere boxes): a leaf visit runs k discriminant tests; counts pair steps,
+ * leaf visits, discriminant tests and tests that reach the fp64 roots. */
+typedef struct { float box[6]; int left, right, first, count; } knode;
+static knode *g_k; static int g_kn, g_leafk, *g_kids;
+static unsigned long long k_pairs, k_visits, k_disc, k_roots, k_mismatch, k_bottom;
+static int leafk_build(int *ids, int n) {
+    const int me = g_kn++;
+    float bb[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};
+    for (int i = 0; i < n; i++) grow(bb, g_pbox + 6 * ids[i]);
+    memcpy(g_k[me].box, bb, sizeof bb);
+    if (n <= g_leafk) { g_k[me].left = -1; g_k[me].first = (int)(ids - g_kids); g_k[me].count = n; return me; }
+    float best = 1e30f; int best_axis = 0, best_k = n / 2;
+    int *tmp = malloc(n * sizeof(int)); float *ra = malloc(n * sizeof(float));
+    for (int a = 0; a < 3; a++) {
+        memcpy(tmp, ids, n * sizeof(int)); g_cmp_axis = a; qsort(tmp, n, sizeof(int), cmp_prim);
+        float rb[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};
+        for (int i = n - 1; i > 0; i--) { grow(rb, g_pbox + 6 * tmp[i]); ra[i] = area(rb); }
+        float lb[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};
+        for (int k = 1; k < n; k++) {
+            grow(lb, g_pbox + 6 * tmp[k - 1]);
+            const float cost = area(lb) * k + ra[k] * (n - k);
+            if (cost < best) { best = cost; best_axis = a; best_k = k; }
+        }
+    }
+    g_cmp_axis = best_axis; qsort(ids, n, sizeof(int), cmp_prim);
+    free(tmp); free(ra);
+    const int l = leafk_build(ids, best_k), r = leafk_build(ids + best_k, n - best_k);
+    g_k[me].left = l; g_k[me].right = r;
+    return me;
+}
+static void leafk_ray(const ray *r, float c_ref, int prim_ref) {
+    float c = 1e30f; int p = -1;
+    int stack[128]; int sp = 0;
+    int cur = 0; float e0;
+    if (!box_test(g_k[0].box, r, 0.001f, 1e30f, &e0)) cur = -1;
+    while (cur >= 0) {
+        const knode *n = &g_k[cur];
+        int next = -1;
+        if (n->left < 0) {
+            k_visits++;
+            for (int q = 0; q < n->count; q++) {
+                const int prim = g_kids[n->first + q];
+                const rt_sphere *s = &g_scn->spheres[prim];
+                k_disc++;
+                { v3 oc = sub(r->o, from_rt(s->center)); float a = lensq(r->d), hb = dot(oc, r->d), cc = lensq(oc) - s->radius * s->radius; if (hb * hb - a * cc >= 0) k_roots++; }
+                hitrec tmp;
+                if (hit_sphere(r, 0.001f, c, &tmp, s)) { c = tmp.t; p = prim; }
+            }
+        } else {
+            float el, er; k_pairs++;
+            if (g_k[n->left].left < 0 && g_k[n->right].left < 0) k_bottom++;
+            const float cl = c + g_beta * c;
+            const int hl = box_test(g_k[n->left].box, r, 0.001f, cl, &el), hr = box_test(g_k[n->right].box, r, 0.001f, cl, &er);
+            if (hl && hr) { const int lf = el <= er; stack[sp++] = lf ? n->right : n->left; next = lf ? n->left : n->right; }
+            else if (hl) next = n->left;
+            else if (hr) next = n->right;
+        }
+        if (next < 0) { if (sp == 0) break; next = stack[--sp]; }
+        cur = next;
+    }
+    if ((p != prim_ref) || (p >= 0 && c != c_ref)) k_mismatch++;
+}
 static float fill_rmax(int i) {
     if (g_s[i].left < 0) return g_rmax[i] = g_scn->spheres[g_s[i].prim].radius;
     const float a = fill_rmax(g_s[i].left), b = fill_rmax(g_s[i].right);
@@ -378,6 +443,8 @@ int main(int argc, char **argv) {
     snode *sn = malloc(sizeof(snode) * 2 * sc.num_spheres);
     g_s = sn; g_sn = 0; sah_build(ids, sc.num_spheres); g_rmax = malloc(sizeof(float) * g_sn); fill_rmax(0); g_s_any = sn;
     if (getenv("DEFER")) { g_defer = atoi(getenv("DEFER")); g_defer_on = 1; }
+    if (getenv("LEAFK")) { g_leafk = atoi(getenv("LEAFK")); g_kids = malloc(sizeof(int) * sc.num_spheres); for (int i = 0; i < sc.num_spheres; i++) g_kids[i] = i;
+        g_k = malloc(sizeof(knode) * 2 * sc.num_spheres); g_kn = 0; leafk_build(g_kids, sc.num_spheres); g_leafk_on = 1; printf("LEAFK tree: %d nodes\n", g_kn); }
     if (getenv("WIDE")) { g_w = calloc(g_sn, sizeof(wnode)); wide_build(0); g_w_any = g_w; }
     float *fb = malloc((size_t)W * H * 3 * sizeof(float));
     orc_render(&sc, &cam, 0, H, fb, 1, NULL);
@@ -398,6 +465,8 @@ int main(int argc, char **argv) {
     }
     if (g_defer_on) printf("DEFER (parked leaf, tested after %d pair steps): pair steps/ray %.2f  leaf tests/ray %.2f  mismatches (unguarded) %llu\n", g_defer,
                            (double)df_pairs / n_rays, (double)df_leaf / n_rays, df_mismatch);
+    if (g_leafk_on) printf("LEAFK=%d: pair steps/ray %.2f (bottom pairs %.2f)  leaf visits/ray %.2f  discriminants/ray %.2f  reaching roots/ray %.2f  mismatches (unguarded) %llu\n", g_leafk,
+                           (double)k_pairs / n_rays, (double)k_bottom / n_rays, (double)k_visits / n_rays, (double)k_disc / n_rays, (double)k_roots / n_rays, k_mismatch);
     printf("  max pending-stack depth per ray:");
     for (int i = 0; i < 24; i++) if (depth_hist[i]) printf(" %d:%.4f%%", i, 100.0 * depth_hist[i] / n_rays);
     printf("\n");
