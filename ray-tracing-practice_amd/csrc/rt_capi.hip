@@ -898,6 +898,37 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
     return RT_OK;
 }
 
+// Developer hook (not part of the ABI header): the proof by exhaustion behind rt_device_math.h's recip() and sqrt_cr().
+// Runs every one of the 2^32 binary32 bit patterns through them on the current device and counts the inputs whose result
+// differs in any bit from the compiler's correctly rounded 1.0f / x and sqrtf(x) (NaN results count as equal to NaN).
+// out[0]: mismatches of recip, out[1]: of sqrt_cr, out[2]: inputs compared.  Both must be 0.
+namespace rtk {
+__global__ void __launch_bounds__(256) fast_math_check_kernel(unsigned long long *out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    unsigned long long bad_r = 0, bad_s = 0, seen = 0;
+    for (uint64_t b = tid; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float wr = 1.0f / x, gr = rtd::recip(x);
+        const float ws = sqrtf(x), gs = rtd::sqrt_cr(x);
+        bad_r += (__float_as_uint(wr) != __float_as_uint(gr)) && !(wr != wr && gr != gr);
+        bad_s += (__float_as_uint(ws) != __float_as_uint(gs)) && !(ws != ws && gs != gs);
+        ++seen;
+    }
+    atomicAdd(&out[0], bad_r); atomicAdd(&out[1], bad_s); atomicAdd(&out[2], seen);
+}
+}  // namespace rtk
+rt_status rt_debug_check_fast_math(uint64_t out[3]) {
+    if (!out) return fail(RT_ERR_INVALID_ARG, "null argument");
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 24));
+    hipError_t e = hipMemset(d, 0, 24);
+    if (e == hipSuccess) { hipLaunchKernelGGL(rtk::fast_math_check_kernel, dim3(4096), dim3(256), 0, 0, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(out, d, 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(e);
+    return RT_OK;
+}
+
 // Developer hook (not part of the ABI header): raw counters of an RTP_STATS build.
 rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[16]) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARG, "null argument");

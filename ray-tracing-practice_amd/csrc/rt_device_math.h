@@ -43,10 +43,45 @@ RT_HD float lensq(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }          /
 RT_HD f3 cross(f3 a, f3 b) {                                                   // include/vec3.h:101-103
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// ---- correctly rounded 1/t and sqrt(t) ---------------------------------------------------------
+// On the host: the C operators.  On gfx950 the compiler's correctly rounded forms (-fhip-fp32-correctly-rounded-divide-sqrt:
+// v_div_scale / v_rcp / four fma / v_div_fmas / v_div_fixup; v_sqrt plus a two-sided residual test) cost 58 and 62 cycles of
+// SIMD time per wave, a v_fma_f32 2.8 (tools/micro/valu_rates.hip) — and a shade step holds a dozen of them.  One hardware
+// estimate + one fused correction gives THE SAME BITS for every input whose exponent is not extreme:
+//     1/t:      r = v_rcp_f32(t);  r += r * fma(-t, r, 1)                  for |t| in [2^-126, 2^126)
+//     sqrt(t):  r = v_rsq_f32(t);  s = t*r;  s += (r/2) * fma(-s, s, t)    for  t  in [2^-102, 2^128)
+// checked on the device for ALL 2^32 inputs (rt_debug_check_fast_math, tests/test_gpu_parity.py: zero mismatches with the
+// range fence below; tools/micro/exact_rcp_sqrt.hip prints where the unfenced sequences differ: only biased exponents 0
+// and 253-255 for 1/t, 0-24 and 255 for sqrt).  Inputs outside the fence — zero, denormals, infinities, NaN, huge — take
+// the compiler's sequence in a branch the wave skips when no lane needs it.
+#ifndef RTP_FAST_RCP_SQRT
+#define RTP_FAST_RCP_SQRT 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && RTP_FAST_RCP_SQRT
+__device__ __forceinline__ float recip_estimate(float t) {          // exact where recip_in_fence(t)
+    const float r = __builtin_amdgcn_rcpf(t);
+    return __builtin_fmaf(__builtin_fmaf(-t, r, 1.0f), r, r);
+}
+__device__ __forceinline__ bool recip_in_fence(float t) { return (__float_as_uint(t) & 0x7fffffffu) - 0x00800000u < 0x7e000000u; }
+__device__ __forceinline__ float recip(float t) {
+    float r = recip_estimate(t);
+    if (__builtin_expect(!recip_in_fence(t), 0)) r = 1.0f / t;
+    return r;
+}
+__device__ __forceinline__ float sqrt_cr(float t) {
+    const float r = __builtin_amdgcn_rsqf(t);
+    const float s0 = t * r, h = 0.5f * r;
+    float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, t), h, s0);
+    if (__builtin_expect(!(__float_as_uint(t) - 0x0c800000u < 0x73000000u), 0)) s = sqrtf(t);
+    return s;
+}
+#else
 // (1.0 / t) narrowed to float == 1.0f / t (single correctly rounded operation, see header).
 RT_HD float recip(float t) { return 1.0f / t; }
+RT_HD float sqrt_cr(float t) { return sqrtf(t); }
+#endif
 RT_HD f3 divs(f3 v, float t) { return scale(recip(t), v); }                    // include/vec3.h:97
-RT_HD f3 unit(f3 v) { return divs(v, sqrtf(lensq(v))); }                       // include/vec3.h:105
+RT_HD f3 unit(f3 v) { return divs(v, sqrt_cr(lensq(v))); }                     // include/vec3.h:105
 RT_HD bool near_zero(f3 a) {                                                   // include/vec3.h:58-61
     const float s = 1e-8f;
     return (fabsf(a.x) < s) && (fabsf(a.y) < s) && (fabsf(a.z) < s);
@@ -55,7 +90,7 @@ RT_HD f3 reflect(f3 v, f3 n) { return sub(v, scale(2.0f * dot(v, n), n)); }    /
 RT_HD f3 refract(f3 v, f3 n, float eta) {                                      // include/vec3.h:65-70
     const float cos_theta = fminf(dot(neg(v), n), 1.0f);
     const f3 perp = scale(eta, add(v, scale(cos_theta, n)));
-    const f3 par = scale(-sqrtf(fabsf(1.0f - lensq(perp))), n);
+    const f3 par = scale(-sqrt_cr(fabsf(1.0f - lensq(perp))), n);
     return add(perp, par);
 }
 

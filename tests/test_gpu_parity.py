@@ -862,3 +862,19 @@ def test_hit_scene_on_crafted_rays():
     assert np.array_equal(hit, ohit)
     h = hit == 1
     assert np.array_equal(t[h].view(np.uint32), ot[h].view(np.uint32)) and np.array_equal(prim[h], oprim[h])
+
+
+@pytest.mark.gpu
+def test_fast_reciprocal_and_sqrt_match_ieee_for_every_float():
+    """rt_device_math.h recip() / sqrt_cr(): a hardware estimate plus one fused correction inside an exponent fence, the
+    compiler's correctly rounded sequence outside it.  Proof by exhaustion on the device that renders: all 2^32 binary32
+    inputs, every result bit compared with 1.0f / x and sqrtf(x) (the reference's own operations, include/vec3.h:97,105)."""
+    import ctypes as C
+    lib = rb.amd_lib()
+    out = (C.c_uint64 * 3)()
+    lib.rt_debug_check_fast_math.argtypes = [C.POINTER(C.c_uint64)]
+    lib.rt_debug_check_fast_math.restype = C.c_int
+    assert lib.rt_debug_check_fast_math(out) == 0
+    assert out[2] == 2 ** 32
+    assert out[0] == 0, "recip() differs from 1.0f / x for %d inputs" % out[0]
+    assert out[1] == 0, "sqrt_cr() differs from sqrtf(x) for %d inputs" % out[1]

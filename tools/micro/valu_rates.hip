@@ -40,6 +40,17 @@
 #define I_CVTU(r) "v_cvt_u32_f32 " #r ", " #r "\n"
 #define I_FMAMIX(r) "v_fmac_f32 " #r ", %8, %9\n"
 #define I_RSQ(r) "v_rsq_f32 " #r ", " #r "\n"
+#define I_DIVSCALE(r) "v_div_scale_f32 " #r ", vcc, " #r ", %8, " #r "\n"
+#define I_DIVFMAS(r) "v_div_fmas_f32 " #r ", " #r ", %8, %9\n"
+#define I_DIVFIXUP(r) "v_div_fixup_f32 " #r ", " #r ", %8, %9\n"
+#define I_CMPCLASS(r) "v_cmp_class_f32 vcc, " #r ", %8\n"
+#define I_FREXP(r) "v_frexp_mant_f32 " #r ", " #r "\n"
+#define I_LDEXP(r) "v_ldexp_f32 " #r ", " #r ", %8\n"
+#define I_FLOOR(r) "v_floor_f32 " #r ", " #r "\n"
+#define I_BFI(r) "v_bfi_b32 " #r ", " #r ", %8, %9\n"
+#define I_ASHR(r) "v_ashrrev_i32 " #r ", 3, " #r "\n"
+#define I_SUBU(r) "v_sub_u32 " #r ", " #r ", %8\n"
+#define I_LSHLADD64(r) "v_lshl_add_u64 %0, %0, 4, %0\n"
 #define I_SNOP(r) "s_nop 0\n"
 #define I_SALU(r) "s_and_b64 s[20:21], s[20:21], exec\n"
 #define I_MBCNT(r) "v_mbcnt_lo_u32_b32 " #r ", %10, " #r "\n"
@@ -66,7 +77,9 @@ template <int kMode> __global__ void __launch_bounds__(768, 2) k(uint32_t *out, 
     else if (kMode == 28) BODY(I_LSHL) else if (kMode == 29) BODY(I_CMPI) else if (kMode == 30) BODY(I_CMPE64) else if (kMode == 31) BODY(I_ADD3)
     else if (kMode == 32) BODY(I_XAD) else if (kMode == 33) BODY(I_MULHI) else if (kMode == 34) BODY(I_MAD24) else if (kMode == 35) BODY(I_CVTU)
     else if (kMode == 36) BODY(I_FMAMIX) else if (kMode == 37) BODY(I_RSQ) else if (kMode == 38) BODY(I_SNOP) else if (kMode == 39) BODY(I_SALU)
-    else if (kMode == 40) BODY(I_MBCNT) else if (kMode == 41) BODY(I_READLANE)
+    else if (kMode == 40) BODY(I_MBCNT) else if (kMode == 41) BODY(I_READLANE) else if (kMode == 42) BODY(I_DIVSCALE) else if (kMode == 43) BODY(I_DIVFMAS)
+    else if (kMode == 44) BODY(I_DIVFIXUP) else if (kMode == 45) BODY(I_CMPCLASS) else if (kMode == 46) BODY(I_FREXP) else if (kMode == 47) BODY(I_LDEXP)
+    else if (kMode == 48) BODY(I_FLOOR) else if (kMode == 49) BODY(I_BFI) else if (kMode == 50) BODY(I_ASHR) else if (kMode == 51) BODY(I_SUBU)
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
 }
 
@@ -122,6 +135,29 @@ template <int kMode> static void run(const char *what, uint32_t *o) {
         printf("%-22s %d wave(s)/SIMD: %7.3f ms = %5.2f cycles per instruction per SIMD at 2.4 GHz\n", what, waves, best, best * 1e-3 * 2.4e9 / ((double)iters * 64 * waves)); fflush(stdout);
     }
 }
+__global__ void __launch_bounds__(768, 2) kdiv(float *out, int iters, int mode) {
+    float a = threadIdx.x + 1.5f, b = a * 0.37f + 2.0f, c = b + 3.25f, d = c * 1.5f;
+    for (int i = 0; i < iters; ++i) {
+        if (mode == 0) { a = 1.0f / a + 0.75f; b = 1.0f / b + 0.75f; c = 1.0f / c + 0.75f; d = 1.0f / d + 0.75f; }
+        else if (mode == 1) { a = sqrtf(a) + 1.5f; b = sqrtf(b) + 1.5f; c = sqrtf(c) + 1.5f; d = sqrtf(d) + 1.5f; }
+        else if (mode == 2) { a = (float)(1.0 / (double)a) + 0.75f; b = (float)(1.0 / (double)b) + 0.75f; c = (float)(1.0 / (double)c) + 0.75f; d = (float)(1.0 / (double)d) + 0.75f; }
+        else { a = __builtin_amdgcn_rcpf(a) + 0.75f; b = __builtin_amdgcn_rcpf(b) + 0.75f; c = __builtin_amdgcn_rcpf(c) + 0.75f; d = __builtin_amdgcn_rcpf(d) + 0.75f; }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d;
+}
+static void rundiv(const char *what, uint32_t *o, int mode) {
+    const int iters = 20000;
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEvent_t s, e; (void)hipEventCreate(&s); (void)hipEventCreate(&e);
+        (void)hipEventRecord(s);
+        hipLaunchKernelGGL(kdiv, dim3(512), dim3(768), 0, 0, (float *)o, iters, mode);
+        (void)hipEventRecord(e); (void)hipEventSynchronize(e);
+        float ms; (void)hipEventElapsedTime(&ms, s, e);
+        if (ms < best) best = ms;
+    }
+    printf("%-44s %7.3f ms = %6.1f cycles per operation (+1 add) per SIMD at 2.4 GHz\n", what, best, best * 1e-3 * 2.4e9 / ((double)iters * 4 * 6)); fflush(stdout);
+}
 int main() {
     uint32_t *o; (void)hipMalloc(&o, 512 * 768 * 4);
     run<0>("v_fma_f32", o); run<1>("v_add_f32", o); run<2>("v_min_f32", o); run<3>("v_max3_f32", o); run<4>("v_xor_b32", o);
@@ -132,7 +168,10 @@ int main() {
     run<24>("v_and_b32", o); run<25>("v_or_b32", o); run<26>("v_and_or_b32", o); run<27>("v_bfe_u32", o); run<28>("v_lshlrev_b32", o); run<29>("v_cmp_lt_i32", o);
     run<30>("v_cmp_gt_f32_e64", o); run<31>("v_add3_u32", o); run<32>("v_xad_u32", o); run<33>("v_mul_hi_u32", o); run<34>("v_mad_u32_u24", o); run<35>("v_cvt_u32_f32", o);
     run<36>("v_fmac_f32", o); run<37>("v_rsq_f32", o); run<38>("s_nop 0", o); run<39>("s_and_b64", o); run<40>("v_mbcnt_lo", o); run<41>("v_readfirstlane", o);
+    run<42>("v_div_scale_f32", o); run<43>("v_div_fmas_f32", o); run<44>("v_div_fixup_f32", o); run<45>("v_cmp_class_f32", o); run<46>("v_frexp_mant_f32", o);
+    run<47>("v_ldexp_f32", o); run<48>("v_floor_f32", o); run<49>("v_bfi_b32", o); run<50>("v_ashrrev_i32", o); run<51>("v_sub_u32", o);
     run64<0>("v_pk_add_f32", o); run64<1>("v_pk_mul_f32", o); run64<2>("v_pk_fma_f32", o); run64<3>("v_rcp_f64", o); run64<4>("v_fma_f64", o); run64<5>("v_add_f64", o);
     run64<6>("v_mul_f64", o); run64<7>("v_div_scale_f64", o); run64<8>("v_div_fmas_f64", o); run64<9>("v_div_fixup_f64", o); run64<10>("v_cvt_f64_f32", o); run64<11>("v_cvt_f32_f64", o);
+    rundiv("1.0f / x (IEEE, -fhip-fp32-correctly-rounded-divide-sqrt)", o, 0); rundiv("sqrtf(x) (IEEE)", o, 1); rundiv("(float)(1.0 / (double)x)", o, 2); rundiv("v_rcp_f32", o, 3);
     return 0;
 }
