@@ -792,6 +792,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             // near-first walk; samples it cannot vouch for go to the list …
             P.stack_levels = fast.stack_levels;
             P.num_top = fast.num_top;
+            // vote thresholds of the octant walk (its pair steps are cheaper, so a block of them is worth starting for fewer
+            // idle lanes and a shade step is worth waiting for a few more): re-swept after step_octant, +1.0 %
+            const bool octant_launch = (RTP_OCTANT != 0) && fast.in_lds && !wide && !wavefront && !dyn;
+            if (octant_launch && sc->cfg.k_inner <= 0) P.k_inner = 32;
+            if (octant_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
             P.flag_list = sc->flag_list;
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
@@ -816,6 +821,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
             // … and are walked again in the reference's order, overwriting their slab entries
             rtk::KParams R = P;
+            R.k_inner = sc->cfg.k_inner > 0 ? sc->cfg.k_inner : 24;
+            R.k_shade = sc->cfg.k_shade > 0 ? sc->cfg.k_shade : 48;
             R.queue = sc->queue + kQueueRework + pass;
             R.work_list = sc->flag_list;
             R.work_count = sc->queue + kQueueFlag + pass;
@@ -917,6 +924,48 @@ __global__ void __launch_bounds__(256) fast_math_check_kernel(unsigned long long
     atomicAdd(&out[0], bad_r); atomicAdd(&out[1], bad_s); atomicAdd(&out[2], seen);
 }
 }  // namespace rtk
+// The same for test_sphere's root selection (rt_kernel.hip.inc, sphere_root: both quotients from one fp64 reciprocal, no
+// scaling): n operand sets (half_b, D, a, closest) — half of them raw random bit patterns (every exponent, infinities, NaN,
+// denormals, zeros), half with exponents near the scene's scale — through sphere_root and through sphere_root_plain, the
+// reference's form with the compiler's division.  out[0]: sets where "accepted" differs or the accepted t differs in any
+// bit, out[1]: sets with an accepted root, out[2]: sets compared.
+namespace rtk {
+__global__ void __launch_bounds__(256) sphere_root_check_kernel(unsigned long long *out, unsigned long long n) {
+    const uint64_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, hits = 0, seen = 0;
+    for (uint64_t i = tid; i < n; i += stride) {
+        uint32_t h = rtd::wang_hash((uint32_t)i ^ 0x9e3779b9u) + (uint32_t)(i >> 32) * 0x85ebca6bu;
+        uint32_t w[4];
+        for (int k = 0; k < 4; ++k) { h = rtd::wang_hash(h + 0x632be5abu * (k + 1)); w[k] = h; }
+        if (i & 1) {            // exponents within 2^-20 .. 2^20 of 1, random mantissas and signs
+            for (int k = 0; k < 4; ++k) w[k] = (w[k] & 0x807fffffu) | ((107u + ((w[k] >> 23) & 255u) % 41u) << 23);
+        }
+        const float half_b = __uint_as_float(w[0]);
+        const float disc = __uint_as_float(w[1] & 0x7fffffffu);          // test_sphere has returned for D < 0
+        const float a = __uint_as_float(w[2] & 0x7fffffffu);             // a = |d|^2
+        const float closest = __uint_as_float(w[3] & 0x7fffffffu);
+        const double sq = (double)rtd::sqrt_cr(disc), nb = (double)(-half_b), da = (double)a;
+        float tf = 0.0f, tp = 0.0f;
+        const bool of = sphere_root(nb, sq, da, closest, tf), op = sphere_root_plain(nb, sq, da, closest, tp);
+        bad += (of != op) || (of && __float_as_uint(tf) != __float_as_uint(tp));
+        hits += op;
+        ++seen;
+    }
+    atomicAdd(&out[0], bad); atomicAdd(&out[1], hits); atomicAdd(&out[2], seen);
+}
+}  // namespace rtk
+rt_status rt_debug_check_sphere_roots(uint64_t n, uint64_t out[3]) {
+    if (!out) return fail(RT_ERR_INVALID_ARG, "null argument");
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 24));
+    hipError_t e = hipMemset(d, 0, 24);
+    if (e == hipSuccess) { hipLaunchKernelGGL(rtk::sphere_root_check_kernel, dim3(4096), dim3(256), 0, 0, d, (unsigned long long)n); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(out, d, 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(e);
+    return RT_OK;
+}
+
 rt_status rt_debug_check_fast_math(uint64_t out[3]) {
     if (!out) return fail(RT_ERR_INVALID_ARG, "null argument");
     unsigned long long *d = nullptr;

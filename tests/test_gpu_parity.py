@@ -878,3 +878,19 @@ def test_fast_reciprocal_and_sqrt_match_ieee_for_every_float():
     assert out[2] == 2 ** 32
     assert out[0] == 0, "recip() differs from 1.0f / x for %d inputs" % out[0]
     assert out[1] == 0, "sqrt_cr() differs from sqrtf(x) for %d inputs" % out[1]
+
+
+@pytest.mark.gpu
+def test_sphere_roots_from_one_reciprocal_match_the_plain_divisions():
+    """test_sphere's root selection (both fp64 quotients from one v_rcp_f64 + Newton steps, no scaling instructions) against
+    the reference's form with the compiler's correctly rounded divisions, on 2^32 operand sets: raw random bit patterns
+    (all exponents, inf, NaN, denormals) and scene-scale operands alike — same acceptance, same accepted root, bit for bit."""
+    import ctypes as C
+    lib = rb.amd_lib()
+    out = (C.c_uint64 * 3)()
+    lib.rt_debug_check_sphere_roots.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.rt_debug_check_sphere_roots.restype = C.c_int
+    assert lib.rt_debug_check_sphere_roots(2 ** 32, out) == 0
+    assert out[2] == 2 ** 32
+    assert out[1] > 2 ** 26          # accepted roots are really being produced and compared
+    assert out[0] == 0, "%d operand sets differ" % out[0]
