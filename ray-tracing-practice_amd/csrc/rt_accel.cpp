@@ -1,4 +1,5 @@
 #include "rt_accel.h"
+#include "rt_device_math.h"      // schlick_r0sq: the packer evaluates it with the arithmetic the kernel would use
 
 #include <algorithm>
 #include <cmath>
@@ -818,7 +819,13 @@ std::string Packer::primitive_tables() {
         o[4] = m.emit.e[0]; o[5] = m.emit.e[1]; o[6] = m.emit.e[2]; o[7] = m.fuzz;
         // DIELECTRIC never reads fuzz: its slot carries the refraction ratio of a front-face hit, (float)(1.0 / ir)
         // (include/materials.h:100), so the kernel's glass branch has one division less
-        if (m.type == RT_MAT_DIELECTRIC) o[7] = static_cast<float>(1.0 / static_cast<double>(m.ir));
+        if (m.type == RT_MAT_DIELECTRIC) {
+            o[7] = static_cast<float>(1.0 / static_cast<double>(m.ir));
+            // … and never reads albedo either (its attenuation starts from 1): slots 0 and 1 carry Schlick's r0^2
+            // (include/materials.h:65-66) for the two refraction ratios a hit can have, front (1/ir) and back (ir)
+            o[0] = rtd::schlick_r0sq(o[7]);
+            o[1] = rtd::schlick_r0sq(m.ir);
+        }
         o[8] = m.absorption.e[0]; o[9] = m.absorption.e[1]; o[10] = m.absorption.e[2]; o[11] = m.ir;
     }
     size_t texels = 0;

@@ -190,6 +190,13 @@ RT_HD float pow5(float x) {
     return (float)(d2 * d2 * d);
 }
 
+// Schlick's r0^2 for a refraction ratio (the first two lines of reflectance()): made once per material and side by the
+// packer (rt_accel.cpp keeps both in the albedo slots a DIELECTRIC never reads), so the kernel's glass branch has no division.
+RT_HD float schlick_r0sq(float ref_idx) {
+    const float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    return r0 * r0;
+}
+RT_HD float reflectance_from_r0sq(float cosine, float r0) { return r0 + (1.0f - r0) * pow5(1.0f - cosine); }
 RT_HD float reflectance(float cosine, float ref_idx) {     // include/materials.h:64-68
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
