@@ -349,6 +349,7 @@ void rt_config_from_env(rt_config *cfg) {
     cfg->wavefront_exchange = env_int("RTP_WF_EXCHANGE", cfg->wavefront_exchange);
     if (env_int("RTP_NO_TAPER", 0)) cfg->reserve_taper = 0;
     cfg->wide_nodes = env_int("RTP_WIDE", cfg->wide_nodes);
+    if (env_int("RTP_NO_SIMPLE", 0)) cfg->sphere_only_kernel = -1;
 }
 
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) { return rt_scene_create_ex(desc, nullptr, out_scene); }
@@ -538,8 +539,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     // 4-wide nodes where the scene has them (host-built tree with at least one inner node) and the configuration does not
     // ask for the pair nodes; the wavefront kernel walks pairs
     const bool wide = sc->wnodes != nullptr && sc->num_wide > 0 && cfg.wide_nodes != 0 && !want_wavefront;
-    const uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
-    const int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
+    uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
+    int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
+    // the sphere-only build of the octant walk (render_kernel<…, kSimple>): 1024-thread workgroups, 8 waves per SIMD
+    bool simple = false;
     if (guarded) {
         // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
         // spheres for origins within sqrt(d0_sq) of their cluster: a camera outside either gets the tree re-packed
@@ -565,10 +568,27 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         // fp32 records when LDS-resident: 7 float4 per wide node, 4 per pair node — 5 in the octant layout the kernel stages
         // for the pair walk with static margins (rt_kernel.hip.inc, step_octant)
         const bool octant = (RTP_OCTANT != 0) && !wide && !want_wavefront && !(sc->guard.dyn_k > 0.0f);
-        const uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * (octant ? 5 : 4)) + prim_f4) * 16;
+        uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * (octant ? 5 : 4)) + prim_f4) * 16;
         const int32_t deepest = wide ? 3 * sc->wide_depth : sc->tree_depth;          // a wide node leaves up to three children waiting
         const int32_t want = deepest + 1 > 2 ? deepest + 1 : 2;       // never overflows
-        const uint32_t per_level = gblock * 4u;
+        uint32_t per_level = gblock * 4u;
+        // sphere-only build: no planes, no textures, leaf boxes recomputed from the spheres; its LDS holds no material rows
+        // (all three come from global memory), which pays for the wider stack rows of 1024 lanes
+        simple = octant && cfg.scene_in_lds != 0 && cfg.sphere_only_kernel >= 0 && P.num_planes == 0 && sc->tex_data == nullptr &&
+                 P.leaf_boxes == nullptr && cfg.workgroups_per_cu == 0;
+        if (simple) {
+            const uint64_t simple_bytes = ((uint64_t)P.num_internal * 5 + (uint64_t)P.num_spheres + ((uint64_t)P.num_spheres + 3) / 4) * 16;
+            const uint64_t budget = kLdsLimit / 2;
+            const int64_t fit = simple_bytes + pool_bytes + 64 < budget ? (int64_t)((budget - simple_bytes - pool_bytes - 64) / ((uint64_t)rtk::kSimpleBlock * 4u)) : 0;
+            if (fit >= 6 || fit >= want) {          // at least the sentinel + 5 levels: below that the re-walk launch eats the gain
+                gblock = (uint32_t)rtk::kSimpleBlock;
+                gwgs_per_cu = rtk::kSimpleWaves * 256 / rtk::kSimpleBlock;
+                table_bytes = simple_bytes + ((uint64_t)(rtk::kSimpleBlock / rtk::kWave) * 8u - pool_bytes);      // + the four extra waves' work ranges
+                per_level = gblock * 4u;
+            } else {
+                simple = false;
+            }
+        }
         // tables in LDS when they leave room for a useful stack at full occupancy; else they are read
         // through L1/L2 and LDS holds only the stacks
         auto levels_for = [&](uint64_t scene_bytes, int wgs_per_cu) -> int32_t {
@@ -601,6 +621,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             const int32_t top_have = wide ? sc->num_top_wide : sc->num_top_pairs;
             fast.num_top = (int32_t)(fit < top_have ? fit : top_have);
         }
+        if (!fast.in_lds || fast.wgs_per_cu != gwgs_per_cu) simple = false;      // (cannot happen after the fit test above; the general kernel is always right)
         fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32)) + pool_bytes + (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
     }
@@ -704,6 +725,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kBlock), lds, stream, KP);
         return hipGetLastError();
     };
+    auto launch_simple = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kSimpleBlock), lds, stream, KP);
+        return hipGetLastError();
+    };
     auto launch_wf = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -771,7 +798,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         // with an atomic per 64 samples was the bottleneck of the whole kernel (5.05 -> 6.25 Gsamples/s with
         // 512 per atomic); small frames keep at least 16 reservations per wave so the tail stays balanced.
         {
-            const uint64_t waves_total = (uint64_t)wgs * ((wavefront ? rtk::kWfBlock : rtk::kBlock) / rtk::kWave);
+            const uint64_t waves_total = (uint64_t)wgs * ((wavefront ? rtk::kWfBlock : (guarded && simple ? rtk::kSimpleBlock : rtk::kBlock)) / rtk::kWave);
             uint64_t per = (uint64_t)P.total_work / (waves_total * 16u * 64u);
             per = per < 1 ? 1 : (per > 8 ? 8 : per);
             if (const int forced = cfg.reserve_chunk) per = (uint64_t)(forced > 0 ? forced : 1);
@@ -816,7 +843,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             } else if (dyn) {
                 if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true>, P, wgs, fast.lds_bytes));
-            } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
+            } else if (fast.in_lds && simple) HIP_TRY(launch_simple(rtk::render_kernel<true, false, false, false, true>, P, wgs, fast.lds_bytes));
+            else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
             else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
             if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
             // … and are walked again in the reference's order, overwriting their slab entries
@@ -847,7 +875,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->timed = true;
     sc->last = rt_timing{};
     sc->last.num_workgroups = (uint32_t)wgs;
-    sc->last.workgroup_size = wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;
+    sc->last.workgroup_size = wavefront ? (uint32_t)rtk::kWfBlock : (guarded && simple ? (uint32_t)rtk::kSimpleBlock : (uint32_t)rtk::kBlock);
     sc->last.lds_bytes = main_shape.lds_bytes;
 #ifdef RTP_DEV_QUEUE_KERNEL
     if (use_queue) { sc->last.workgroup_size = rtk::kQBlock; sc->last.lds_bytes = q_lds; }

@@ -78,7 +78,8 @@ class Config(C.Structure):
                 ("pass_spp", C.c_int32), ("stack_levels", C.c_int32), ("flag_capacity", C.c_uint32), ("scene_in_lds", C.c_int32),
                 ("lds_treelet", C.c_int32), ("workgroups_per_cu", C.c_int32), ("k_inner", C.c_int32), ("k_shade", C.c_int32),
                 ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
-                ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32)]
+                ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32),
+                ("sphere_only_kernel", C.c_int32)]
 
 
 class ConfigInfo(C.Structure):
