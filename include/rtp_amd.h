@@ -148,6 +148,7 @@ typedef struct rt_timing {
     uint32_t kernel;          /* RT_KERNEL_* actually used */
     uint32_t guard_dynamic;   /* 1: the guarded walk ran with distance-aware margins (rt_config.guard_dynamic_margins) */
     uint32_t wide_nodes;      /* 1: the guarded walk ran on 4-wide nodes */
+    uint32_t sphere_only;     /* 1: the sphere-only build of the guarded kernel ran (rt_config.sphere_only_kernel) */
 } rt_timing;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */

@@ -888,6 +888,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last.kernel = wavefront ? RT_KERNEL_WAVEFRONT : RT_KERNEL_MEGA;
     sc->last.guard_dynamic = dyn ? 1u : 0u;
     sc->last.wide_nodes = (guarded && wide) ? 1u : 0u;
+    sc->last.sphere_only = (guarded && simple && !wavefront && !wide && !dyn) ? 1u : 0u;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);

@@ -9,7 +9,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-ma
 mkdir -p ../profiles/$ROUND
 {
   echo "# hipcc $FLAGS -Rpass-analysis=kernel-resource-usage -c csrc/rt_capi.hip   ($(/opt/rocm/bin/hipcc --version | head -1))"
-  echo "# render_kernel<kLds, kThreaded, kDyn, kWide>: <true,false,false,false> = the headline trace kernel, <true,true,…> = the exact re-walk"
+  echo "# render_kernel<kLds, kThreaded, kDyn, kWide, kSimple>: <true,false,false,false,true> = the headline trace kernel (sphere-only build), <true,false,false,false,false> = the general octant kernel, <true,true,…> = the exact re-walk"
   grep -E "Function Name|TotalSGPRs|VGPRs:|AGPRs|ScratchSize|Occupancy|SGPRs Spill|VGPRs Spill|LDS Size" /tmp/rt_capi_ru.txt | sed 's/.*remark: //;s/ \[-Rpass-analysis=kernel-resource-usage\]//' | sed 's/^    /  /' | c++filt
 } > ../profiles/$ROUND/kernel_resource_usage.txt
 wc -l ../profiles/$ROUND/kernel_resource_usage.txt

@@ -17,7 +17,9 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(float)
 for f in glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'render_kernel' in r['Kernel_Name'] and ('false>' in r['Kernel_Name'] or '_wf' in r['Kernel_Name']):
+        kn = r['Kernel_Name']
+        args = [a.strip() for a in kn.split('<', 1)[1].split('>', 1)[0].split(',')] if 'render_kernel<' in kn else []
+        if (len(args) > 1 and args[1] == 'false') or '_wf' in kn:      # the guarded trace kernel (kThreaded = false), not the exact re-walk
             acc[r['Counter_Name']] += float(r['Counter_Value'])
 tot = acc.get('SQ_INSTS_VALU', 1.0)
 for k in sorted(acc):
