@@ -579,11 +579,11 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (simple) {
             const uint64_t simple_bytes = ((uint64_t)P.num_internal * 5 + (uint64_t)P.num_spheres + ((uint64_t)P.num_spheres + 3) / 4) * 16;
             const uint64_t budget = kLdsLimit / 2;
-            const int64_t fit = simple_bytes + pool_bytes + 64 < budget ? (int64_t)((budget - simple_bytes - pool_bytes - 64) / ((uint64_t)rtk::kSimpleBlock * 4u)) : 0;
+            const int64_t fit = simple_bytes + pool_bytes + 256 < budget ? (int64_t)((budget - simple_bytes - pool_bytes - 256) / ((uint64_t)rtk::kSimpleBlock * 4u)) : 0;
             if (fit >= 6 || fit >= want) {          // at least the sentinel + 5 levels: below that the re-walk launch eats the gain
                 gblock = (uint32_t)rtk::kSimpleBlock;
                 gwgs_per_cu = rtk::kSimpleWaves * 256 / rtk::kSimpleBlock;
-                table_bytes = simple_bytes + ((uint64_t)(rtk::kSimpleBlock / rtk::kWave) * 8u - pool_bytes);      // + the four extra waves' work ranges
+                table_bytes = simple_bytes + ((uint64_t)(rtk::kSimpleBlock / rtk::kWave) * 8u - pool_bytes) + 16 * rtk::kConstRows;      // + the four extra waves' work ranges + the constants block
                 per_level = gblock * 4u;
             } else {
                 simple = false;
