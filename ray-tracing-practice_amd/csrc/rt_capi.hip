@@ -568,7 +568,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         // fp32 records when LDS-resident: 7 float4 per wide node, 4 per pair node — 5 in the octant layout the kernel stages
         // for the pair walk with static margins (rt_kernel.hip.inc, step_octant)
         const bool octant = (RTP_OCTANT != 0) && !wide && !want_wavefront && !(sc->guard.dyn_k > 0.0f);
-        uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * (octant ? 5 : 4)) + prim_f4) * 16;
+        uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * (octant ? 5 : 4)) + prim_f4) * 16 +
+                               (octant && RTP_CONSTS_ALL ? 16u * rtk::kConstRows : 0u);      // + the octant kernel's constants block
         const int32_t deepest = wide ? 3 * sc->wide_depth : sc->tree_depth;          // a wide node leaves up to three children waiting
         const int32_t want = deepest + 1 > 2 ? deepest + 1 : 2;       // never overflows
         uint32_t per_level = gblock * 4u;
