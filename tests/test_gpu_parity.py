@@ -505,6 +505,26 @@ def test_config_api_without_environment():
     assert_same_frame(fb, want, "workspace for 64 spp per pass: two passes of 35")
 
 
+def test_sphere_only_kernel_and_general_kernel_give_the_same_frame():
+    """rt_config.sphere_only_kernel: a scene without planes and textures is rendered by the sphere-only build of the octant
+    kernel (1024-thread workgroups, 8 waves per SIMD, reported in rt_timing.sphere_only); -1 forces the general build.  Same
+    frame, which is the oracle's; a scene WITH a plane never gets the sphere-only build."""
+    host = rb.HostScene.rtiow()
+    cam = rb.rtiow_camera(320, 180, 24, 50)
+    want = ob.render(host, cam, threads=8)
+    fast = rb.DeviceScene(host, device=0, honour_env=False)
+    fb, t = fast.render_to_host(cam)
+    assert t.guarded == 1 and t.sphere_only == 1 and t.workgroup_size == 1024, (t.guarded, t.sphere_only, t.workgroup_size)
+    assert_same_frame(fb, want, "sphere-only build")
+    general = rb.DeviceScene(host, device=0, honour_env=False, sphere_only_kernel=-1)
+    fb2, t2 = general.render_to_host(cam)
+    assert t2.guarded == 1 and t2.sphere_only == 0 and t2.workgroup_size == 768
+    assert_same_frame(fb2, want, "general build")
+    quad = rb.DeviceScene(rb.HostScene.rtiow(half_extent=3, textured_quad=True, texture_size=64), device=0, honour_env=False)
+    _, t3 = quad.render_to_host(rb.rtiow_camera(64, 36, 4, 8))
+    assert t3.sphere_only == 0
+
+
 def test_guarded_walk_flags_and_rewalks(rtiow, force_guarded):
     """The guarded near-first walk hands a small share of the samples (far origins, hits in front of
     their own leaf box, a full stack) to the exact walk; with a 2-entry stack it hands over many
