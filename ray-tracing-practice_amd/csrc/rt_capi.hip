@@ -801,7 +801,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         {
             const uint64_t waves_total = (uint64_t)wgs * ((wavefront ? rtk::kWfBlock : (guarded && simple ? rtk::kSimpleBlock : rtk::kBlock)) / rtk::kWave);
             uint64_t per = (uint64_t)P.total_work / (waves_total * 16u * 64u);
-            per = per < 1 ? 1 : (per > 8 ? 8 : per);
+            per = per < 1 ? 1 : (per > 16 ? 16 : per);      // 1024 per atomic with 8192 waves: +1 % over 512 (32: the same, 64: the tail shows)
             if (const int forced = cfg.reserve_chunk) per = (uint64_t)(forced > 0 ? forced : 1);
             P.chunk = (uint32_t)(64u * per);
             P.taper_shift = 1;                      // remaining / (2 x waves), rounded to a power of two
