@@ -198,6 +198,8 @@ typedef struct rt_config {
     int32_t  sphere_only_kernel;  /* 0 (default): scenes without planes and textures whose tables fit LDS are rendered by the
                                      sphere-only build of the guarded kernel (64 registers per lane, 8 waves per SIMD instead of
                                      6; the same frame bit for bit); -1: always the general kernel */
+    int32_t  overlap_rework;      /* 0 (default): the exact re-walk of flagged samples and the accumulation of their pixels run on a
+                                     second stream of the handle beside the accumulation of all other pixels; -1: one after the other */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */

@@ -56,7 +56,8 @@ constexpr int kTimedPasses = 64;        // trace launches individually timed per
 // Counter block of a scene handle (uint32 words): work counters of the trace launches, of the exact
 // re-walk launches, the flagged-sample counts (one each per pass), then 16 developer words.
 constexpr int kQueueWork = 0, kQueueRework = kMaxPasses, kQueueFlag = 2 * kMaxPasses, kQueueStats = 3 * kMaxPasses;
-constexpr int kQueueWords = 3 * kMaxPasses + 16;
+constexpr int kQueueDirty = 3 * kMaxPasses + 16;      // per pass: pixels with a flagged sample (overlapped re-walk)
+constexpr int kQueueWords = 4 * kMaxPasses + 16;
 
 // Traversal (rt_config.traversal).  EXACT ("threaded"): the caller's tree in the reference's own visit order — the
 // result is the reference's by construction.  GUARDED (AUTO's choice where the scene is eligible): near-first walk
@@ -138,6 +139,12 @@ struct rt_scene {
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
+    // overlapped re-walk: the exact re-walk + the accumulation of the pixels it touches run on aux_stream beside the
+    // accumulation of all other pixels on the caller's stream
+    uint32_t *dirty = nullptr, *dirty_list = nullptr;      // per local pixel: mark, list of marked pixels
+    size_t dirty_cap = 0;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float4 *wf_pool = nullptr;      // render_kernel_wf: ray/hit stacks of every resident wave, grown on demand
     size_t wf_pool_float4s = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
@@ -350,6 +357,7 @@ void rt_config_from_env(rt_config *cfg) {
     if (env_int("RTP_NO_TAPER", 0)) cfg->reserve_taper = 0;
     cfg->wide_nodes = env_int("RTP_WIDE", cfg->wide_nodes);
     if (env_int("RTP_NO_SIMPLE", 0)) cfg->sphere_only_kernel = -1;
+    if (env_int("RTP_NO_OVERLAP", 0)) cfg->overlap_rework = -1;
 }
 
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) { return rt_scene_create_ex(desc, nullptr, out_scene); }
@@ -460,6 +468,10 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
     (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list); (void)hipFree(sc->wf_pool);
+    (void)hipFree(sc->dirty); (void)hipFree(sc->dirty_list);
+    if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
+    if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
+    if (sc->ev_join) (void)hipEventDestroy(sc->ev_join);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
@@ -688,6 +700,20 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             HIP_TRY(hipMalloc((void **)&sc->flag_list, cap * sizeof(uint32_t)));
             sc->flag_cap = cap;
         }
+        if (cfg.overlap_rework >= 0 && sc->dirty_cap < (size_t)num_pixels) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(sc->dirty); (void)hipFree(sc->dirty_list);
+            sc->dirty = sc->dirty_list = nullptr;
+            sc->dirty_cap = 0;
+            HIP_TRY(hipMalloc((void **)&sc->dirty, (size_t)num_pixels * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **)&sc->dirty_list, (size_t)num_pixels * sizeof(uint32_t)));
+            sc->dirty_cap = (size_t)num_pixels;
+        }
+        if (cfg.overlap_rework >= 0 && !sc->aux_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
+        }
     }
 
     // kernel form of the guarded pass: render_kernel (a lane owns a path) or render_kernel_wf (a wave owns a pool of paths)
@@ -720,11 +746,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     int wgs = grid_for(main_shape);
 
     HIP_TRY(hipMemsetAsync(sc->queue, 0, kQueueWords * 4, stream));
+    const bool overlap = guarded && !wavefront && !use_queue && cfg.overlap_rework >= 0 && sc->aux_stream != nullptr && sc->dirty != nullptr;
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
+    hipStream_t launch_stream = stream;       // the exact re-walk may go to the handle's second stream (overlap_rework)
     auto launch = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kBlock), lds, stream, KP);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kBlock), lds, launch_stream, KP);
         return hipGetLastError();
     };
     auto launch_simple = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
@@ -828,6 +856,10 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             if (octant_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
             P.flag_list = sc->flag_list;
             P.flag_count = sc->queue + kQueueFlag + pass;
+            P.dirty = overlap ? sc->dirty : nullptr;
+            if (overlap) HIP_TRY(hipMemsetAsync(sc->dirty, 0, (size_t)num_pixels * sizeof(uint32_t), stream));      // this pass's marks (8 MB at 1080p: microseconds)
+            P.dirty_list = overlap ? sc->dirty_list : nullptr;
+            P.dirty_count = sc->queue + kQueueDirty + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
             if (const uint32_t tiny = cfg.flag_capacity) P.flag_cap = tiny < P.flag_cap ? tiny : P.flag_cap;   // test hook: overflow path
             if (wavefront) {
@@ -859,18 +891,38 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             R.work_cap = P.flag_cap;
             R.chunk = 64u;                     // a short list: finest granularity
             R.taper_shift = 0;
+            R.dirty = nullptr;
+            if (overlap) {
+                // the re-walk and the accumulation of the pixels it touches on the second stream …
+                HIP_TRY(hipEventRecord(sc->ev_fork, stream));
+                HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_fork, 0));
+                launch_stream = sc->aux_stream;
+            }
             HIP_TRY(launch_exact(R, grid_for(exact)));
+            launch_stream = stream;
         } else {
             HIP_TRY(launch_exact(P, wgs));
         }
+        const bool overlapped = overlap && guarded && !wavefront;
         if (timed_pass) {
             if (!guarded) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
-            HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 2], stream));
+            HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 2], overlapped ? sc->aux_stream : stream));
             sc->timed_passes = pass + 1;
         }
         // … then added to the pixel sums strictly in sample order
-        hipLaunchKernelGGL(rtk::accumulate_kernel, dim3((num_pixels + 64 * rtk::kAccWaves - 1) / (64 * rtk::kAccWaves)), dim3(64 * rtk::kAccWaves), 0, stream, d_fb_sum,
-                           (const float *)sc->slab, num_pixels, P.slab_pitch, P.pass_count, pass == 0 ? 1 : 0);
+        const dim3 acc_grid((num_pixels + 64 * rtk::kAccWaves - 1) / (64 * rtk::kAccWaves)), acc_block(64 * rtk::kAccWaves);
+        if (overlapped) {
+            hipLaunchKernelGGL(rtk::accumulate_kernel<true>, acc_grid, acc_block, 0, sc->aux_stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
+                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)sc->dirty_list, (const uint32_t *)(sc->queue + kQueueDirty + pass));
+            HIP_TRY(hipEventRecord(sc->ev_join, sc->aux_stream));
+            // … while every other pixel is accumulated here
+            hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
+                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+            HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join, 0));
+        } else {
+            hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
+                               P.pass_count, pass == 0 ? 1 : 0, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_stop, stream));

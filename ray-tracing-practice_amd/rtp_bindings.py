@@ -80,7 +80,7 @@ class Config(C.Structure):
                 ("lds_treelet", C.c_int32), ("workgroups_per_cu", C.c_int32), ("k_inner", C.c_int32), ("k_shade", C.c_int32),
                 ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
                 ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32),
-                ("sphere_only_kernel", C.c_int32)]
+                ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32)]
 
 
 class ConfigInfo(C.Structure):

@@ -525,6 +525,27 @@ def test_sphere_only_kernel_and_general_kernel_give_the_same_frame():
     assert t3.sphere_only == 0
 
 
+def test_overlapped_rewalk_gives_the_same_frame():
+    """rt_config.overlap_rework: by default the exact re-walk and the accumulation of the pixels it touches run on the handle's
+    second stream beside the accumulation of all other pixels; -1 runs them one after the other.  Same frame (the oracle's),
+    also over several passes and with a stack so short that a sixth of the samples is flagged."""
+    host = rb.HostScene.rtiow()
+    cam = rb.rtiow_camera(256, 144, 200, 50)
+    want = ob.render(host, cam, threads=8)
+    for kw, what in ((dict(), "default"), (dict(pass_spp=64), "four passes"), (dict(pass_spp=64, stack_levels=3), "four passes, short stack")):
+        on = rb.DeviceScene(host, device=0, honour_env=False, **kw)
+        fb, t = on.render_to_host(cam)
+        assert t.guarded == 1 and t.flagged_samples > 0
+        assert_same_frame(fb, want, "overlapped, " + what)
+        off = rb.DeviceScene(host, device=0, honour_env=False, overlap_rework=-1, **kw)
+        fb2, t2 = off.render_to_host(cam)
+        assert t2.flagged_samples > 0          # (not necessarily the same count: which samples a parked test flags depends on when the wave ran its leaf steps)
+        assert_same_frame(fb2, want, "sequential, " + what)
+    # the same handle again (marks and lists of the previous frame must not leak into the next)
+    fb3, _ = on.render_to_host(cam)
+    assert_same_frame(fb3, want, "second frame on the same handle")
+
+
 def test_guarded_walk_flags_and_rewalks(rtiow, force_guarded):
     """The guarded near-first walk hands a small share of the samples (far origins, hits in front of
     their own leaf box, a full stack) to the exact walk; with a 2-entry stack it hands over many
