@@ -246,7 +246,9 @@ int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard);
  * Limits: at most 2^24 pixels per call (rt_shard_rows() x image_width; 4K = 2^23) and samples_per_pixel <= 65536 —
  * RT_ERR_UNSUPPORTED beyond.  The scene must have been created on the calling thread's current device
  * (RT_ERR_INVALID_ARG otherwise).  One handle renders one frame at a time: calls on the same handle must be
- * issued to the same stream or separated by a synchronisation. */
+ * issued to the same stream or separated by a synchronisation.  (With rt_config.overlap_rework the handle runs part of a
+ * pass on a second, non-blocking stream of its own; that stream is forked from and joined to hip_stream with events inside the
+ * call, so to the caller everything still happens in hip_stream's order.) */
 rt_status rt_render(rt_scene *scene, const rt_camera_data *cam, const rt_shard *shard,
                     float *d_fb_sum, void *hip_stream, int32_t sync, rt_timing *timing);
 

@@ -43,7 +43,7 @@ def means(name):
     for r in csv.DictReader(open(os.path.join(dst, f"pmc_{name}.csv"))):
         kn = r["Kernel_Name"]
         kind = ("trace" if MAIN.startswith(kn) or kn.startswith(MAIN) else "rework" if "render_kernel" in kn
-                else "accumulate" if "accumulate_kernel" in kn else None)
+                else "accumulate_list" if "accumulate_kernel<true>" in kn else "accumulate" if "accumulate_kernel" in kn else None)
         if kind is None:
             continue
         key = (kind, r["Counter_Name"])
@@ -70,6 +70,7 @@ traffic = {
     "bytes_per_trace_launch": int((2 * f[("trace", "FETCH_SIZE")] + w[("trace", "WRITE_SIZE")]) * 1024),
     "bytes_per_rework_launch": int((2 * f.get(("rework", "FETCH_SIZE"), 0) + w.get(("rework", "WRITE_SIZE"), 0)) * 1024),
     "bytes_per_accumulate_launch": int((2 * f[("accumulate", "FETCH_SIZE")] + w[("accumulate", "WRITE_SIZE")]) * 1024),
+    "bytes_per_accumulate_list_launch": int((2 * f.get(("accumulate_list", "FETCH_SIZE"), 0.0) + w.get(("accumulate_list", "WRITE_SIZE"), 0.0)) * 1024),
 }
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 
