@@ -581,7 +581,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         // for the pair walk with static margins (rt_kernel.hip.inc, step_octant)
         const bool octant = (RTP_OCTANT != 0) && !wide && !want_wavefront && !(sc->guard.dyn_k > 0.0f);
         uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * (octant ? 5 : 4)) + prim_f4) * 16 +
-                               (RTP_CONSTS_ALL && !want_wavefront ? 16u * rtk::kConstRows : 0u);      // + the guarded kernels' constants block
+                               (!want_wavefront ? 16u * rtk::kConstRows : 0u);      // + the guarded kernels' constants block
         const int32_t deepest = wide ? 3 * sc->wide_depth : sc->tree_depth;          // a wide node leaves up to three children waiting
         const int32_t want = deepest + 1 > 2 ? deepest + 1 : 2;       // never overflows
         uint32_t per_level = gblock * 4u;
@@ -629,13 +629,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
         if (!fast.in_lds && cfg.lds_treelet) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
-            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (RTP_CONSTS_ALL && !want_wavefront ? 16u * rtk::kConstRows : 0u);
+            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);
             const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;
             const int32_t top_have = wide ? sc->num_top_wide : sc->num_top_pairs;
             fast.num_top = (int32_t)(fit < top_have ? fit : top_have);
         }
         if (!fast.in_lds || fast.wgs_per_cu != gwgs_per_cu) simple = false;      // (cannot happen after the fit test above; the general kernel is always right)
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (RTP_CONSTS_ALL && !want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (!want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
                                     (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
     }
