@@ -525,6 +525,20 @@ def test_sphere_only_kernel_and_general_kernel_give_the_same_frame():
     assert t3.sphere_only == 0
 
 
+def test_frame_sizes_from_one_pixel_to_the_limit():
+    """rt_render's limits and corner sizes through the sphere-only kernel: the largest frame it accepts (2^24 pixels), 4K, one
+    pixel, one sample per pixel (the index arithmetic's d == 1 case) — first, middle and last image row against the oracle."""
+    host = rb.HostScene.rtiow()
+    for (w, h, spp) in ((4096, 4096, 2), (3840, 2160, 4), (64, 64, 1), (1, 1, 3), (7, 3, 65)):
+        cam = rb.rtiow_camera(w, h, spp, 50)
+        dev = rb.DeviceScene(host, device=0, honour_env=False)
+        fb, t = dev.render_to_host(cam)
+        assert t.guarded == 1 and t.sphere_only == 1
+        for r in sorted({0, h // 2, h - 1}):
+            want = ob.render(host, cam, row0=r, row1=r + 1, threads=8)
+            assert np.array_equal(want.view(np.uint32), fb[r:r + 1].view(np.uint32)), (w, h, spp, r)
+
+
 def test_overlapped_rewalk_gives_the_same_frame():
     """rt_config.overlap_rework: by default the exact re-walk and the accumulation of the pixels it touches run on the handle's
     second stream beside the accumulation of all other pixels; -1 runs them one after the other.  Same frame (the oracle's),
