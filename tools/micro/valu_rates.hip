@@ -51,6 +51,8 @@
 #define I_ASHR(r) "v_ashrrev_i32 " #r ", 3, " #r "\n"
 #define I_SUBU(r) "v_sub_u32 " #r ", " #r ", %8\n"
 #define I_LSHLADD64(r) "v_lshl_add_u64 %0, %0, 4, %0\n"
+#define I_FMAMIXH(r) "v_fma_mix_f32 " #r ", " #r ", %8, %9 op_sel_hi:[1,0,0]\n"
+#define I_CVTH(r) "v_cvt_f32_f16 " #r ", " #r "\n"
 #define I_SNOP(r) "s_nop 0\n"
 #define I_SALU(r) "s_and_b64 s[20:21], s[20:21], exec\n"
 #define I_MBCNT(r) "v_mbcnt_lo_u32_b32 " #r ", %10, " #r "\n"
@@ -79,6 +81,7 @@ template <int kMode> __global__ void __launch_bounds__(768, 2) k(uint32_t *out, 
     else if (kMode == 36) BODY(I_FMAMIX) else if (kMode == 37) BODY(I_RSQ) else if (kMode == 38) BODY(I_SNOP) else if (kMode == 39) BODY(I_SALU)
     else if (kMode == 40) BODY(I_MBCNT) else if (kMode == 41) BODY(I_READLANE) else if (kMode == 42) BODY(I_DIVSCALE) else if (kMode == 43) BODY(I_DIVFMAS)
     else if (kMode == 44) BODY(I_DIVFIXUP) else if (kMode == 45) BODY(I_CMPCLASS) else if (kMode == 46) BODY(I_FREXP) else if (kMode == 47) BODY(I_LDEXP)
+    else if (kMode == 52) BODY(I_FMAMIXH) else if (kMode == 53) BODY(I_CVTH)
     else if (kMode == 48) BODY(I_FLOOR) else if (kMode == 49) BODY(I_BFI) else if (kMode == 50) BODY(I_ASHR) else if (kMode == 51) BODY(I_SUBU)
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
 }
@@ -170,6 +173,7 @@ int main() {
     run<36>("v_fmac_f32", o); run<37>("v_rsq_f32", o); run<38>("s_nop 0", o); run<39>("s_and_b64", o); run<40>("v_mbcnt_lo", o); run<41>("v_readfirstlane", o);
     run<42>("v_div_scale_f32", o); run<43>("v_div_fmas_f32", o); run<44>("v_div_fixup_f32", o); run<45>("v_cmp_class_f32", o); run<46>("v_frexp_mant_f32", o);
     run<47>("v_ldexp_f32", o); run<48>("v_floor_f32", o); run<49>("v_bfi_b32", o); run<50>("v_ashrrev_i32", o); run<51>("v_sub_u32", o);
+    run<52>("v_fma_mix_f32 (f16 src)", o); run<53>("v_cvt_f32_f16", o);
     run64<0>("v_pk_add_f32", o); run64<1>("v_pk_mul_f32", o); run64<2>("v_pk_fma_f32", o); run64<3>("v_rcp_f64", o); run64<4>("v_fma_f64", o); run64<5>("v_add_f64", o);
     run64<6>("v_mul_f64", o); run64<7>("v_div_scale_f64", o); run64<8>("v_div_fmas_f64", o); run64<9>("v_div_fixup_f64", o); run64<10>("v_cvt_f64_f32", o); run64<11>("v_cvt_f32_f64", o);
     rundiv("1.0f / x (IEEE, -fhip-fp32-correctly-rounded-divide-sqrt)", o, 0); rundiv("sqrtf(x) (IEEE)", o, 1); rundiv("(float)(1.0 / (double)x)", o, 2); rundiv("v_rcp_f32", o, 3);
