@@ -149,6 +149,8 @@ typedef struct rt_timing {
     uint32_t guard_dynamic;   /* 1: the guarded walk ran with distance-aware margins (rt_config.guard_dynamic_margins) */
     uint32_t wide_nodes;      /* 1: the guarded walk ran on 4-wide nodes */
     uint32_t sphere_only;     /* 1: the sphere-only build of the guarded kernel ran (rt_config.sphere_only_kernel) */
+    uint32_t primary_visibility; /* 1: camera rays were resolved by the per-pixel candidate pass (rt_config.primary_visibility) */
+    float    primary_ms;      /* … its launches' hipEvent durations (candidate lists + one pass per trace launch) */
 } rt_timing;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */
@@ -200,6 +202,9 @@ typedef struct rt_config {
                                      6; the same frame bit for bit); -1: always the general kernel */
     int32_t  overlap_rework;      /* 0 (default): the exact re-walk of flagged samples and the accumulation of their pixels run on a
                                      second stream of the handle beside the accumulation of all other pixels; -1: one after the other */
+    int32_t  primary_visibility;  /* 0 (default): where the guarded walk's tables are LDS-resident, the first hit of every camera ray
+                                     comes from a per-pixel candidate list (the leaves the pixel's cone of rays can reach, made once per
+                                     frame) instead of a walk per sample — the same frame bit for bit; -1: camera rays walk the tree */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */

@@ -14,6 +14,7 @@
 #include "rt_build.h"
 #include "rt_device_math.h"
 #include "rt_kernel.hip.inc"
+#include "rt_primary.hip.inc"
 #include "rt_kernel_wf.hip.inc"
 #ifdef RTP_DEV_QUEUE_KERNEL      // developer build only (make DEV=1): the slower T-wave/S-wave LDS-queue experiment, DESIGN.md §5b
 #include "rt_kernel_queue.hip.inc"
@@ -145,6 +146,8 @@ struct rt_scene {
     size_t dirty_cap = 0;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t *cand = nullptr;       // primary visibility: per local pixel rtk::kCandWords words (candidate leaves), grown on demand
+    size_t cand_pixels = 0;
     float4 *wf_pool = nullptr;      // render_kernel_wf: ray/hit stacks of every resident wave, grown on demand
     size_t wf_pool_float4s = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
@@ -358,6 +361,7 @@ void rt_config_from_env(rt_config *cfg) {
     cfg->wide_nodes = env_int("RTP_WIDE", cfg->wide_nodes);
     if (env_int("RTP_NO_SIMPLE", 0)) cfg->sphere_only_kernel = -1;
     if (env_int("RTP_NO_OVERLAP", 0)) cfg->overlap_rework = -1;
+    if (env_int("RTP_NO_PRIMARY", 0)) cfg->primary_visibility = -1;
 }
 
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) { return rt_scene_create_ex(desc, nullptr, out_scene); }
@@ -468,7 +472,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->spheres); (void)hipFree(sc->planes); (void)hipFree(sc->materials);
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
     (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list); (void)hipFree(sc->wf_pool);
-    (void)hipFree(sc->dirty); (void)hipFree(sc->dirty_list);
+    (void)hipFree(sc->dirty); (void)hipFree(sc->dirty_list); (void)hipFree(sc->cand);
     if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
     if (sc->ev_join) (void)hipEventDestroy(sc->ev_join);
@@ -747,7 +751,29 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
 
     HIP_TRY(hipMemsetAsync(sc->queue, 0, kQueueWords * 4, stream));
     const bool overlap = guarded && !wavefront && !use_queue && cfg.overlap_rework >= 0 && sc->aux_stream != nullptr && sc->dirty != nullptr;
+    // Primary visibility without a walk (rt_primary.hip.inc): the LDS-resident octant walk with static margins, and a camera
+    // inside the distance those margins were sized for (so that the far-origin test can never fire for a camera ray; the
+    // device compares in float: a hair of slack)
+    bool prim = guarded && !wavefront && !use_queue && !wide && !dyn && (RTP_OCTANT != 0) && fast.in_lds && cfg.primary_visibility >= 0 && sc->nodes != nullptr;
+    if (prim && sc->guard.num_small > 0) {
+        const double dx = (double)cam->origin.e[0] - sc->guard.center[0], dy = (double)cam->origin.e[1] - sc->guard.center[1], dz = (double)cam->origin.e[2] - sc->guard.center[2];
+        if (!(dx * dx + dy * dy + dz * dz <= (double)sc->guard.d0_sq * (1.0 - 1e-5))) prim = false;
+    }
+    if (prim && sc->cand_pixels < (size_t)num_pixels) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(sc->cand);
+        sc->cand = nullptr;
+        sc->cand_pixels = 0;
+        HIP_TRY(hipMalloc((void **)&sc->cand, (size_t)num_pixels * rtk::kCandWords * sizeof(uint32_t)));
+        sc->cand_pixels = (size_t)num_pixels;
+    }
+    P.cand = prim ? sc->cand : nullptr;
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
+    if (prim) {
+        const double coord_max = rtbeam::coord_bound(cam->origin.e, cam->pixel00_loc.e, cam->pixel_delta_u.e, cam->pixel_delta_v.e, cam->image_width, cam->image_height);
+        hipLaunchKernelGGL(rtk::cand_kernel, dim3((num_pixels + 255u) / 256u), dim3(256), 0, stream, P, sc->cand, coord_max);
+        HIP_TRY(hipGetLastError());
+    }
     hipStream_t launch_stream = stream;       // the exact re-walk may go to the handle's second stream (overlap_rework)
     auto launch = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -773,7 +799,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (exact.in_lds) return launch(rtk::render_kernel<true, true>, KP, grid, exact.lds_bytes);
         return launch(rtk::render_kernel<false, true>, KP, grid, exact.lds_bytes);
     };
-    while ((int)sc->pass_events.size() < 3 * (passes < kTimedPasses ? passes : kTimedPasses)) {
+    while ((int)sc->pass_events.size() < 4 * (passes < kTimedPasses ? passes : kTimedPasses)) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         sc->pass_events.push_back(e);
@@ -815,7 +841,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     for (int pass = 0; pass < passes; ++pass) {
         // samples [pass_first, pass_first + pass_count) of every pixel, traced in any order into the slab …
         const bool timed_pass = pass < kTimedPasses;
-        if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass], stream));
+        if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[4 * pass], stream));
         P.pass_first = pass * pass_size;
         P.pass_count = P.spp - P.pass_first < pass_size ? P.spp - P.pass_first : pass_size;
         P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
@@ -837,6 +863,16 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             while (((uint64_t)1 << P.taper_shift) < 2 * waves_total) ++P.taper_shift;
             if (!cfg.reserve_taper) P.taper_shift = 0;
         }
+        if (prim) {
+            // primary visibility of this pass's samples: (hit distance, primitive) into each sample's slot of the slab
+            int pgrid = sc->num_cus * 8;                            // 256-thread workgroups: 8 waves per SIMD
+            const uint32_t batches = (P.total_work + 255u) / 256u;
+            if ((uint32_t)pgrid > batches) pgrid = (int)batches;
+            if (P.num_planes > 0) hipLaunchKernelGGL(rtk::primary_kernel<true>, dim3(pgrid), dim3(256), 0, stream, P);
+            else hipLaunchKernelGGL(rtk::primary_kernel<false>, dim3(pgrid), dim3(256), 0, stream, P);
+            HIP_TRY(hipGetLastError());
+        }
+        if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[4 * pass + 1], stream));
 #ifdef RTP_DEV_QUEUE_KERNEL
         if (use_queue) {
             P.stack_levels = 0;
@@ -877,10 +913,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             } else if (dyn) {
                 if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true>, P, wgs, fast.lds_bytes));
-            } else if (fast.in_lds && simple) HIP_TRY(launch_simple(rtk::render_kernel<true, false, false, false, true>, P, wgs, fast.lds_bytes));
+            } else if (fast.in_lds && simple && prim) HIP_TRY(launch_simple(rtk::render_kernel<true, false, false, false, true, true>, P, wgs, fast.lds_bytes));
+            else if (fast.in_lds && simple) HIP_TRY(launch_simple(rtk::render_kernel<true, false, false, false, true>, P, wgs, fast.lds_bytes));
+            else if (fast.in_lds && prim) HIP_TRY(launch(rtk::render_kernel<true, false, false, false, false, true>, P, wgs, fast.lds_bytes));
             else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false>, P, wgs, fast.lds_bytes));
             else HIP_TRY(launch(rtk::render_kernel<false, false>, P, wgs, fast.lds_bytes));
-            if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
+            if (timed_pass) HIP_TRY(hipEventRecord(sc->pass_events[4 * pass + 2], stream));
             // … and are walked again in the reference's order, overwriting their slab entries
             rtk::KParams R = P;
             R.k_inner = sc->cfg.k_inner > 0 ? sc->cfg.k_inner : 24;
@@ -905,8 +943,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         }
         const bool overlapped = overlap && guarded && !wavefront;
         if (timed_pass) {
-            if (!guarded) HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 1], stream));
-            HIP_TRY(hipEventRecord(sc->pass_events[3 * pass + 2], overlapped ? sc->aux_stream : stream));
+            if (!guarded) HIP_TRY(hipEventRecord(sc->pass_events[4 * pass + 2], stream));
+            HIP_TRY(hipEventRecord(sc->pass_events[4 * pass + 3], overlapped ? sc->aux_stream : stream));
             sc->timed_passes = pass + 1;
         }
         // … then added to the pixel sums strictly in sample order
@@ -943,6 +981,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last.guard_dynamic = dyn ? 1u : 0u;
     sc->last.wide_nodes = (guarded && wide) ? 1u : 0u;
     sc->last.sphere_only = (guarded && simple && !wavefront && !wide && !dyn) ? 1u : 0u;
+    sc->last.primary_visibility = prim ? 1u : 0u;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);
@@ -955,21 +994,28 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
     if (sc->timed) {
         HIP_TRY(hipEventSynchronize(sc->ev_stop));
         HIP_TRY(hipEventElapsedTime(&sc->last.kernel_ms, sc->ev_start, sc->ev_stop));
-        float sum = 0.0f, rework = 0.0f;
+        float sum = 0.0f, rework = 0.0f, primary = 0.0f;
         for (int p = 0; p < sc->timed_passes; ++p) {
             float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[3 * p], sc->pass_events[3 * p + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p], sc->pass_events[4 * p + 1]));
+            primary += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p + 1], sc->pass_events[4 * p + 2]));
             sum += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[3 * p + 1], sc->pass_events[3 * p + 2]));
+            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p + 2], sc->pass_events[4 * p + 3]));
             rework += ms;
         }
         // passes beyond the individually timed ones are priced at the mean of the timed ones
         if (sc->timed_passes > 0) {
             sum *= (float)sc->last.trace_launches / (float)sc->timed_passes;
             rework *= (float)sc->last.trace_launches / (float)sc->timed_passes;
+            primary *= (float)sc->last.trace_launches / (float)sc->timed_passes;
+            float ms = 0.0f;          // + the per-pixel candidate lists, made once per call before the first pass
+            HIP_TRY(hipEventElapsedTime(&ms, sc->ev_start, sc->pass_events[0]));
+            primary += ms;
         }
         sc->last.trace_ms = sum;
         sc->last.rework_ms = rework;
+        sc->last.primary_ms = sc->last.primary_visibility ? primary : 0.0f;
         if (sc->last.guarded) {
             std::vector<uint32_t> counts((size_t)sc->last_passes);
             HIP_TRY(hipMemcpy(counts.data(), sc->queue + kQueueFlag, counts.size() * 4, hipMemcpyDeviceToHost));

@@ -63,7 +63,7 @@ class Timing(C.Structure):
                 ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("trace_launches", C.c_uint32),
                 ("trace_ms", C.c_float), ("guarded", C.c_uint32), ("flagged_samples", C.c_uint64), ("rework_ms", C.c_float),
                 ("guard_unproven", C.c_uint32), ("kernel", C.c_uint32), ("guard_dynamic", C.c_uint32), ("wide_nodes", C.c_uint32),
-                ("sphere_only", C.c_uint32)]
+                ("sphere_only", C.c_uint32), ("primary_visibility", C.c_uint32), ("primary_ms", C.c_float)]
 
 
 TRAVERSAL_AUTO, TRAVERSAL_EXACT, TRAVERSAL_GUARDED = 0, 1, 2
@@ -80,7 +80,7 @@ class Config(C.Structure):
                 ("lds_treelet", C.c_int32), ("workgroups_per_cu", C.c_int32), ("k_inner", C.c_int32), ("k_shade", C.c_int32),
                 ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
                 ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32),
-                ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32)]
+                ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32), ("primary_visibility", C.c_int32)]
 
 
 class ConfigInfo(C.Structure):

@@ -1,0 +1,125 @@
+// CPU model of the per-pixel candidate lists behind the primary-visibility pass (csrc/rt_beam.h, rt_primary.hip.inc):
+// for pixels of real frames, every primitive that the ORACLE's primitive test can report a hit for — for any sample of the
+// pixel — must be on the pixel's candidate list (or the pixel must have none: overflow), and so must the oracle's closest
+// hit.  The lists are made by exactly the code the device runs (rtbeam::beam_candidates on the packer's pair table).
+//   usage: test_beam [samples_per_pixel]   → "… all ok"
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+#include "../../oracle/rt_oracle.h"
+#include "../../ray-tracing-practice_amd/csrc/rt_accel.h"
+#include "../../ray-tracing-practice_amd/csrc/rt_beam.h"
+#include "../../ray-tracing-practice_amd/host/camera.h"
+#include "../../ray-tracing-practice_amd/host/scene_builder.h"
+#include "../../ray-tracing-practice_amd/host/scene_params.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                         \
+    do {                                                                    \
+        if (!(cond)) { if (failures < 20) std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+// hit_sphere's acceptance (include/sphere.h:24-45) with the widest interval ray_color ever passes: can this ray report a hit?
+static bool sphere_reports_hit(const rt_sphere &s, const float o[3], const float d[3]) {
+    const float oc[3] = {o[0] - s.center.e[0], o[1] - s.center.e[1], o[2] - s.center.e[2]};
+    const float a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const float half_b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
+    const float c = (oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2]) - s.radius * s.radius;
+    const float disc = half_b * half_b - a * c;
+    if (disc < 0) return false;
+    const double sq = std::sqrt((double)disc);
+    float root = (float)(((double)-half_b - sq) / (double)a);
+    if (root >= 0.001f && root <= 1e30f) return true;
+    root = (float)(((double)-half_b + sq) / (double)a);
+    return root >= 0.001f && root <= 1e30f;
+}
+
+struct Stats { long pixels = 0, overflow = 0, cand_sum = 0, cand_max = 0, rays = 0, hits = 0, reported = 0; };
+
+static void check_frame(rtp::HostScene &hs, const rt_camera_data &cam, int step, int spp, int max_out, const char *name, int dynamic = 0) {
+    const rt_scene_desc d = hs.desc();
+    rtaccel::Packed pk;
+    rtaccel::PackOptions opt;
+    opt.dynamic = dynamic;
+    const std::string err = rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk, opt);
+    CHECK(err.empty());
+    if (!pk.guard.ok) { std::printf("%s: not eligible for the guarded walk (%s) — nothing to check\n", name, pk.guard.reason.c_str()); return; }
+    const double cmax = rtbeam::coord_bound(cam.origin.e, cam.pixel00_loc.e, cam.pixel_delta_u.e, cam.pixel_delta_v.e, cam.image_width, cam.image_height);
+    auto nodes = [&](int32_t k) { return &pk.nodes[(size_t)k * 16]; };
+    Stats st;
+    std::vector<uint32_t> cand((size_t)max_out);
+    for (int j = 0; j < cam.image_height; j += step)
+        for (int i = (j / step) % step; i < cam.image_width; i += step) {
+            const rtbeam::Beam b = rtbeam::make_beam(cam.origin.e, cam.pixel00_loc.e, cam.pixel_delta_u.e, cam.pixel_delta_v.e, i, j, cmax);
+            const int n = rtbeam::beam_candidates(b, nodes, pk.root, (double)pk.guard.dyn_k, cand.data(), max_out);
+            st.pixels++;
+            if (n < 0) { st.overflow++; continue; }
+            st.cand_sum += n;
+            st.cand_max = n > st.cand_max ? n : st.cand_max;
+            auto listed = [&](uint32_t code) { for (int k = 0; k < n; ++k) if (cand[(size_t)k] == code) return true; return false; };
+            const uint32_t base = orc_wang_hash((uint32_t)i * (uint32_t)cam.image_width + (uint32_t)j);      // src/camera.cu:25
+            for (int s = 0; s < spp; ++s) {
+                uint32_t seed = orc_wang_hash(base + (uint32_t)s);
+                float o[3], dir[3];
+                orc_get_ray(&cam, i, j, &seed, o, dir);
+                st.rays++;
+                float t; int type, index;
+                if (orc_closest_hit(&d, o, dir, &t, &type, &index)) {
+                    st.hits++;
+                    CHECK(listed((uint32_t)(2 * index + type)));
+                }
+                // the stronger statement the pass relies on: ANY sphere whose test can report a hit is listed
+                for (int q = 0; q < d.num_spheres; ++q)
+                    if (sphere_reports_hit(d.spheres[q], o, dir)) { st.reported++; CHECK(listed((uint32_t)(2 * q))); }
+            }
+        }
+    std::printf("%s: %ld pixels, %ld without a list, %.2f candidates per listed pixel (max %ld), %ld rays, %ld closest hits, %ld reported sphere hits — %s\n",
+                name, st.pixels, st.overflow, st.pixels > st.overflow ? (double)st.cand_sum / (double)(st.pixels - st.overflow) : 0.0, st.cand_max,
+                st.rays, st.hits, st.reported, failures ? "FAILED" : "ok");
+}
+
+static rt_camera_data camera(int w, int h, float vfov, rtp::Vec3 eye, rtp::Vec3 at) {
+    rtp::Camera cam(h, w, nullptr, eye, at);
+    cam.vfov = vfov;
+    cam.samples_per_pixel = 1;
+    cam.max_depth = 50;
+    cam.background_color = rtp::Vec3(0.7f, 0.8f, 1.0f);
+    return cam.build_camera_data();
+}
+
+int main(int argc, char **argv) {
+    const int spp = argc > 1 ? std::atoi(argv[1]) : 6;
+    {
+        rtp::RtiowOptions o;
+        rtp::HostScene hs;
+        rtp::build_rtiow_scene(o, hs);
+        check_frame(hs, camera(1920, 1080, 20.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 37, spp, 15, "S-rtiow 1920x1080");
+        check_frame(hs, camera(96, 64, 20.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 3, spp, 15, "S-rtiow 96x64 (fat pixels)");
+        check_frame(hs, camera(320, 200, 60.0f, rtp::Vec3(0.3f, 0.2f, 0.12f), rtp::Vec3(4, 0, 0.2f)), 7, spp, 15, "S-rtiow, camera between the spheres");
+        check_frame(hs, camera(16, 9, 90.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 1, spp, 15, "S-rtiow 16x9 (many pixels without a list)");
+    }
+    {
+        std::istringstream in(rtp::default_config_text());
+        rtp::SceneParams p = rtp::read_scene_params(in);
+        rtp::HostScene hs;
+        rtp::build_config_scene(p, "", hs);
+        rtp::Vec3 eye, at;
+        rtp::orbit_pose(p, 7, eye, at);
+        check_frame(hs, camera(400, 225, p.fov_degrees, eye, at), 9, spp, 15, "config scene frame 7");
+    }
+    {
+        rtp::RtiowOptions o;
+        o.half_extent = 40;
+        rtp::HostScene hs;
+        rtp::build_rtiow_scene(o, hs);
+        check_frame(hs, camera(640, 360, 20.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 23, spp > 2 ? 2 : spp, 15, "6 k spheres, distance-aware margins", 2);
+    }
+    if (failures) { std::printf("%d failures\n", failures); return 1; }
+    std::printf("all ok\n");
+    return 0;
+}

@@ -9,7 +9,8 @@ ds=rb.DeviceScene(hs,device=0)
 best=1e9
 for it in range(int(os.environ.get('ITERS',4))):
     fb,tm=ds.render_to_host(cam); best=min(best,tm.kernel_ms)
-print('cfg', {k:v for k,v in os.environ.items() if k.startswith('RTP_')}, 'best kernel ms %.3f'%best, 'Msamples/s %.1f'%(W*H*SPP/best/1e3), 'lds',tm.lds_bytes,'wgs',tm.num_workgroups, 'sum', float(fb.sum()))
+print('cfg', {k:v for k,v in os.environ.items() if k.startswith('RTP_')}, 'best kernel ms %.3f'%best, 'Msamples/s %.1f'%(W*H*SPP/best/1e3), 'lds',tm.lds_bytes,'wgs',tm.num_workgroups, 'sum', float(fb.sum()),
+      'trace ms %.3f primary ms %.3f (on %d) rework ms %.3f flagged %d' % (tm.trace_ms, tm.primary_ms, tm.primary_visibility, tm.rework_ms, tm.flagged_samples))
 
 import ctypes as C
 lib=rb.amd_lib()
