@@ -754,7 +754,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     // Primary visibility without a walk (rt_primary.hip.inc): the LDS-resident octant walk with static margins, and a camera
     // inside the distance those margins were sized for (so that the far-origin test can never fire for a camera ray; the
     // device compares in float: a hair of slack)
-    bool prim = guarded && !wavefront && !use_queue && !wide && !dyn && (RTP_OCTANT != 0) && fast.in_lds && cfg.primary_visibility >= 0 && sc->nodes != nullptr;
+    bool prim = guarded && !wavefront && !use_queue && !wide && !dyn && (RTP_OCTANT != 0) && fast.in_lds && cfg.primary_visibility >= 0 && sc->nodes != nullptr &&
+                P.max_depth < rtk::kMaxPrimDepth;
     if (prim && sc->guard.num_small > 0) {
         const double dx = (double)cam->origin.e[0] - sc->guard.center[0], dy = (double)cam->origin.e[1] - sc->guard.center[1], dz = (double)cam->origin.e[2] - sc->guard.center[2];
         if (!(dx * dx + dy * dy + dz * dz <= (double)sc->guard.d0_sq * (1.0 - 1e-5))) prim = false;
@@ -866,9 +867,13 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         if (prim) {
             // primary visibility of this pass's samples: (hit distance, primitive) into each sample's slot of the slab
             int pgrid = sc->num_cus * 8;                            // 256-thread workgroups: 8 waves per SIMD
-            const uint32_t batches = (P.total_work + 255u) / 256u;
-            if ((uint32_t)pgrid > batches) pgrid = (int)batches;
-            if (P.num_planes > 0) hipLaunchKernelGGL(rtk::primary_kernel<true>, dim3(pgrid), dim3(256), 0, stream, P);
+            const bool by_pixel = P.pass_count >= 128;              // a wave per pixel once a pixel fills it at least twice
+            const uint32_t units = by_pixel ? (num_pixels + 3u) / 4u : (P.total_work + 255u) / 256u;
+            if ((uint32_t)pgrid > units) pgrid = (int)units;
+            if (by_pixel) {
+                if (P.num_planes > 0) hipLaunchKernelGGL(rtk::primary_pixel_kernel<true>, dim3(pgrid), dim3(256), 0, stream, P);
+                else hipLaunchKernelGGL(rtk::primary_pixel_kernel<false>, dim3(pgrid), dim3(256), 0, stream, P);
+            } else if (P.num_planes > 0) hipLaunchKernelGGL(rtk::primary_kernel<true>, dim3(pgrid), dim3(256), 0, stream, P);
             else hipLaunchKernelGGL(rtk::primary_kernel<false>, dim3(pgrid), dim3(256), 0, stream, P);
             HIP_TRY(hipGetLastError());
         }

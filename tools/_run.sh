@@ -1,7 +1,6 @@
-export SPP=100
-echo "== default"; python3 tools/perf_sweep.py
-echo "== no primary"; RTP_NO_PRIMARY=1 python3 tools/perf_sweep.py
-echo "== general kernel + primary"; RTP_NO_SIMPLE=1 python3 tools/perf_sweep.py
-echo "== general kernel no primary"; RTP_NO_SIMPLE=1 RTP_NO_PRIMARY=1 python3 tools/perf_sweep.py
-export SPP=500 ITERS=2
-echo "== default 500"; python3 tools/perf_sweep.py
+export SPP=200 ITERS=3
+short() { grep -o "best kernel ms [0-9.]*\|trace ms [0-9.]*\|primary ms [0-9.]*\|flagged [0-9]*" | tr '\n' ' '; echo; }
+echo -n "default 200: "; python3 tools/perf_sweep.py | short
+echo -n "default 500: "; SPP=500 ITERS=2 python3 tools/perf_sweep.py | short
+echo -n "default 100: "; SPP=100 python3 tools/perf_sweep.py | short
+echo "== gpu tests"; timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
