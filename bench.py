@@ -203,6 +203,17 @@ def launcher(args):
 # ------------------------------------------------------------------------------------------------
 # worker: one rank
 # ------------------------------------------------------------------------------------------------
+def cpu_model():
+    """Model string of the host CPU (the CPU baseline states core count AND model)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def host_threads():
     """Host cores this process may use, capped at the 16-core share of a one-GPU box."""
     try:
@@ -246,7 +257,7 @@ def cpu_baseline(host, threads, budget_s=12.0, frame=None, gpu_cam=None):
             np.array_equal(ob.render(host, gpu_cam, row0=r, row1=r + 1, threads=threads).view(np.uint32),
                            frame[r:r + 1].view(np.uint32)) for r in rows))}
     return {
-        "value": round(multi, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "value": round(multi, 3), "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
         "sample": f"oracle render_cpu restatement, full {WIDTH}x{HEIGHT} frame, depth {DEPTH}, {spp} spp "
                   f"({WIDTH * HEIGHT * spp} samples, {dt:.1f} s, {threads} threads); single thread on "
                   f"{n1} samples of the same frame",
@@ -328,24 +339,36 @@ def worker(args):
     local_rows = rb.amd_lib().rt_shard_rows(HEIGHT, C.byref(shard) if shard else None)
     fb = torch.zeros((local_rows, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
+    # every buffer of the collective exists before the timed region (frame_parallel.FrameGatherer)
+    gatherer = fp.FrameGatherer(HEIGHT, WIDTH, band, device=("cpu" if backend != "nccl" else f"cuda:{local_rank}")) if world > 1 else None
 
-    kernel_ms, trace_ms, launches, guarded, flagged, rework_ms = [], [], [], [], [], []
+    kernel_ms, trace_ms, launches, guarded, flagged, rework_ms, primary_ms, gather_ms = [], [], [], [], [], [], [], []
+    last_t = [None]
 
     def step(record):
         dev.render(cam, fb.data_ptr(), shard=shard, stream=stream, sync=False)
+        g0 = 0.0
+        if world > 1 and record:
+            torch.cuda.synchronize()           # (recorded steps only: separates this rank's render from the collective)
+            g0 = time.perf_counter()
         if world > 1 and backend != "nccl":
             torch.cuda.synchronize()
-            frame = fp.gather_frame(fb.cpu(), HEIGHT, band)          # gloo rehearsal: staged through the host
+            frame = gatherer.gather(fb.cpu())                        # gloo rehearsal: staged through the host
         else:
-            frame = fp.gather_frame(fb, HEIGHT, band) if world > 1 else fb
+            frame = gatherer.gather(fb) if world > 1 else fb
         if record:
+            if world > 1:
+                torch.cuda.synchronize()
+                gather_ms.append((time.perf_counter() - g0) * 1e3)
             t = dev.last_timing()     # hipEvent pairs recorded on `stream`: whole call, and around each trace launch
+            last_t[0] = t
             kernel_ms.append(t.kernel_ms)
             trace_ms.append(t.trace_ms)
             launches.append(t.trace_launches)
             guarded.append(t.guarded)
             flagged.append(t.flagged_samples)
             rework_ms.append(t.rework_ms)
+            primary_ms.append(t.primary_ms)
         return frame
 
     def fence():
@@ -368,6 +391,21 @@ def worker(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- second clock: what the reference's own timer brackets besides the kernel — the copy of the float
+    # frame to the host (src/camera.cu:333-343 times render_kernel + cudaMemcpy D2H + the saver loop); never `value`
+    ref_equiv_ms = None
+    host_frame = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
+    fence()
+    t1 = time.perf_counter()
+    reps = min(args.steps, 3)
+    for _ in range(reps):
+        f = step(False)
+        if rank == 0:
+            host_frame.copy_(f)          # blocking device → host copy of the assembled float frame
+    fence()
+    if rank == 0:
+        ref_equiv_ms = (time.perf_counter() - t1) * 1e3 / max(reps, 1)
+
     if rank == 0:
         samples_per_step = WIDTH * HEIGHT * args.spp
         ms_per_step = elapsed * 1e3 / max(args.steps, 1)
@@ -375,7 +413,8 @@ def worker(args):
         out = {
             "metric": "Msamples/sec (pixels x spp / s), path-traced frame",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(ms_per_step, 3), "reference_equivalent_ms": round(ref_equiv_ms, 3) if ref_equiv_ms else None,
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S-rtiow random-sphere scene (486 spheres, 971 BVH nodes, seed 12345), {WIDTH}x{HEIGHT}, "
                                    f"{args.spp} spp, {DEPTH} bounces, background (0.7,0.8,1.0)",
@@ -383,7 +422,8 @@ def worker(args):
                        "collective_backend": (backend if world > 1 else None),
                        "world_size_seen_by_collective": (dist.get_world_size() if world > 1 else 1),
                        "traversal": ("guarded near-first walk + exact re-walk of flagged samples" if guarded and guarded[0]
-                                     else "reference-order (threaded) walk")},
+                                     else "reference-order (threaded) walk"),
+                       "primary_visibility": bool(last_t[0] is not None and last_t[0].primary_visibility)},
         }
         base, st = (None, None)
         if world > 1 and os.environ.get("RTP_BENCH_CHECK"):
@@ -419,10 +459,20 @@ def worker(args):
             "traffic": None,
             "kernel": dev.trace_kernel_name(),
             "launches_per_step": n_launch, "launch_ms": round(launch_ms, 3),
+            "kernel_resources": ({"vgprs_per_lane": int(last_t[0].trace_vgprs), "scratch_bytes_per_lane": int(last_t[0].trace_scratch_bytes),
+                                  "workgroup_size": int(last_t[0].workgroup_size), "workgroups": int(last_t[0].num_workgroups),
+                                  "lds_bytes_per_workgroup": int(last_t[0].lds_bytes),
+                                  "waves_per_simd": int(last_t[0].workgroup_size) // 64 * (int(last_t[0].num_workgroups) // 256) // 4,
+                                  "source": "hipFuncGetAttributes of the loaded code object + the launch shape of this run"}
+                                 if last_t[0] is not None else None),
+            "primary_visibility_pass_ms": round(float(np.mean(primary_ms)), 3) if primary_ms else None,
             "samples_per_launch": local_samples // max(n_launch, 1),
             "rework_launch_ms": round(float(np.mean(rework_ms)) / max(n_launch, 1), 3) if rework_ms else None,
             "flagged_sample_fraction": round(float(np.mean(flagged)) / max(local_samples, 1), 6) if flagged else None,
             "step_kernels_ms": round(k_ms, 3),
+            "per_rank": ({"trace_ms": round(tr_ms, 3), "render_ms": round(k_ms, 3), "gather_ms": round(float(np.mean(gather_ms)), 3),
+                          "note": "rank 0's own render (hipEvents) and the collective as rank 0 sees it (wall clock from its render's end: "
+                                  "includes waiting for the slowest rank)"} if world > 1 else None),
             "hbm_algorithmic_equiv": {
                 "GBps": round(alg, 1), "over_hbm_peak": round(alg / HBM_PEAK_GBS, 3),
                 "bytes_per_sample": round(bytes_per_sample, 1),

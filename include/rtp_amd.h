@@ -151,6 +151,8 @@ typedef struct rt_timing {
     uint32_t sphere_only;     /* 1: the sphere-only build of the guarded kernel ran (rt_config.sphere_only_kernel) */
     uint32_t primary_visibility; /* 1: camera rays were resolved by the per-pixel candidate pass (rt_config.primary_visibility) */
     float    primary_ms;      /* … its launches' hipEvent durations (candidate lists + one pass per trace launch) */
+    uint32_t trace_vgprs;     /* vector registers per lane of the trace kernel that ran, as the loaded code object reports them */
+    uint32_t trace_scratch_bytes; /* … and its scratch (spill) bytes per lane */
 } rt_timing;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */

@@ -776,21 +776,33 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         HIP_TRY(hipGetLastError());
     }
     hipStream_t launch_stream = stream;       // the exact re-walk may go to the handle's second stream (overlap_rework)
+    // registers and scratch of the dominant (trace) kernel as the loaded code object reports them → rt_timing
+    uint32_t trace_vgprs = 0, trace_scratch = 0;
+    auto note_resources = [&](auto kernel) {
+        hipFuncAttributes attr;
+        if (trace_vgprs == 0 && hipFuncGetAttributes(&attr, (const void *)kernel) == hipSuccess) {
+            trace_vgprs = (uint32_t)attr.numRegs;
+            trace_scratch = (uint32_t)attr.localSizeBytes;
+        }
+    };
     auto launch = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        note_resources(kernel);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kBlock), lds, launch_stream, KP);
         return hipGetLastError();
     };
     auto launch_simple = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        note_resources(kernel);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kSimpleBlock), lds, stream, KP);
         return hipGetLastError();
     };
     auto launch_wf = [&](auto kernel, const rtk::KParams &KP, int grid, uint32_t lds) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        note_resources(kernel);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(rtk::kWfBlock), lds, stream, KP);
         return hipGetLastError();
     };
@@ -987,6 +999,8 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     sc->last.wide_nodes = (guarded && wide) ? 1u : 0u;
     sc->last.sphere_only = (guarded && simple && !wavefront && !wide && !dyn) ? 1u : 0u;
     sc->last.primary_visibility = prim ? 1u : 0u;
+    sc->last.trace_vgprs = trace_vgprs;
+    sc->last.trace_scratch_bytes = trace_scratch;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);

@@ -27,43 +27,68 @@ def shard_row_indices(height, band_rows, world_size, rank):
     return rows[(rows // band_rows) % world_size == rank]
 
 
+class FrameGatherer:
+    """The one data-path collective of an N-rank frame, with every buffer made ONCE: the padded send buffer, the per-rank
+    receive buffers and the assembled frame on `dst`, the row indices of every rank.  gather(local_fb) then only copies
+    (when this rank's row count is below the padded size), runs dist.gather (all_gather where the backend has no gather) and
+    scatters the bands to their image rows — nothing is allocated inside a timed loop."""
+
+    def __init__(self, height, width, band_rows=DEFAULT_BAND_ROWS, device="cpu", dtype=torch.float32, group=None, dst=0):
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.height, self.width, self.band_rows = height, width, band_rows
+        self.counts = [len(shard_row_indices(height, band_rows, self.world, r)) for r in range(self.world)]
+        self.pad_rows = max(self.counts)
+        self.device = torch.device(device)
+        self.send = torch.zeros((self.pad_rows, width, 3), dtype=dtype, device=self.device)
+        self.parts = None
+        self.frame = None
+        self.index = None
+        if self.rank == dst or _USE_ALL_GATHER:
+            self._make_receive_side()
+
+    def _make_receive_side(self):
+        if self.parts is None:
+            self.parts = [torch.empty_like(self.send) for _ in range(self.world)]
+        if self.rank == self.dst and self.frame is None:
+            self.frame = torch.empty((self.height, self.width, 3), dtype=self.send.dtype, device=self.device)
+            self.index = [torch.as_tensor(shard_row_indices(self.height, self.band_rows, self.world, r), device=self.device)
+                          for r in range(self.world)]
+
+    def gather(self, local_fb):
+        """local_fb: [local_rows, W, 3] tensor of this rank's rows → the full frame on `dst` (a buffer owned by this object,
+        overwritten by the next call), None elsewhere."""
+        global _USE_ALL_GATHER
+        assert local_fb.shape[0] == self.counts[self.rank] and local_fb.shape[1] == self.width, (local_fb.shape, self.counts, self.rank)
+        if self.world == 1:
+            return local_fb
+        if local_fb.shape[0] == self.pad_rows and local_fb.is_contiguous() and local_fb.device == self.device:
+            send = local_fb
+        else:
+            self.send[:local_fb.shape[0]].copy_(local_fb)
+            send = self.send
+        if not _USE_ALL_GATHER:
+            try:
+                dist.gather(send, self.parts if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                # a backend without gather: every rank takes this branch on the same call (the error is
+                # raised before any communication), then all of them use all_gather from here on
+                _USE_ALL_GATHER = True
+        if _USE_ALL_GATHER:
+            self._make_receive_side()
+            dist.all_gather(self.parts, send, group=self.group)
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world):
+            self.frame.index_copy_(0, self.index[r], self.parts[r][:self.counts[r]])
+        return self.frame
+
+
 def gather_frame(local_fb, height, band_rows, group=None, dst=0):
-    """local_fb: [local_rows, W, 3] float32 tensor of this rank's rows.  Returns the full
+    """One-off form of FrameGatherer.gather (allocates its buffers per call): local_fb [local_rows, W, 3] → the full
     [height, W, 3] frame on `dst`, None elsewhere."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    width = local_fb.shape[1]
-    counts = [len(shard_row_indices(height, band_rows, world, r)) for r in range(world)]
-    assert local_fb.shape[0] == counts[rank], (local_fb.shape, counts, rank)
-    if world == 1:
+    if dist.get_world_size(group) == 1:
         return local_fb
-    pad_rows = max(counts)
-    send = local_fb
-    if send.shape[0] != pad_rows:
-        send = torch.zeros((pad_rows, width, 3), dtype=local_fb.dtype, device=local_fb.device)
-        send[:local_fb.shape[0]] = local_fb
-    send = send.contiguous()
-    global _USE_ALL_GATHER
-    parts = None
-    if not _USE_ALL_GATHER:
-        try:
-            if rank == dst:
-                parts = [torch.empty_like(send) for _ in range(world)]
-                dist.gather(send, parts, dst=dst, group=group)
-            else:
-                dist.gather(send, None, dst=dst, group=group)
-        except (RuntimeError, NotImplementedError):
-            # a backend without gather: every rank takes this branch on the same call (the error is
-            # raised before any communication), then all of them use all_gather from here on
-            _USE_ALL_GATHER = True
-            parts = None
-    if _USE_ALL_GATHER:
-        parts = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(parts, send, group=group)
-    if rank != dst:
-        return None
-    frame = torch.empty((height, width, 3), dtype=local_fb.dtype, device=local_fb.device)
-    for r in range(world):
-        idx = torch.as_tensor(shard_row_indices(height, band_rows, world, r), device=local_fb.device)
-        frame.index_copy_(0, idx, parts[r][:counts[r]])
-    return frame
+    g = FrameGatherer(height, local_fb.shape[1], band_rows, device=local_fb.device, dtype=local_fb.dtype, group=group, dst=dst)
+    return g.gather(local_fb)

@@ -63,7 +63,8 @@ class Timing(C.Structure):
                 ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("trace_launches", C.c_uint32),
                 ("trace_ms", C.c_float), ("guarded", C.c_uint32), ("flagged_samples", C.c_uint64), ("rework_ms", C.c_float),
                 ("guard_unproven", C.c_uint32), ("kernel", C.c_uint32), ("guard_dynamic", C.c_uint32), ("wide_nodes", C.c_uint32),
-                ("sphere_only", C.c_uint32), ("primary_visibility", C.c_uint32), ("primary_ms", C.c_float)]
+                ("sphere_only", C.c_uint32), ("primary_visibility", C.c_uint32), ("primary_ms", C.c_float),
+                ("trace_vgprs", C.c_uint32), ("trace_scratch_bytes", C.c_uint32)]
 
 
 TRAVERSAL_AUTO, TRAVERSAL_EXACT, TRAVERSAL_GUARDED = 0, 1, 2
@@ -350,7 +351,8 @@ class DeviceScene:
         if t.kernel == KERNEL_WAVEFRONT:
             return f"void rtk::render_kernel_wf<{lds}>(rtk::KParams)"
         return (f"void rtk::render_kernel<{lds}, {'false' if t.guarded else 'true'}, {'true' if t.guard_dynamic else 'false'}, "
-                f"{'true' if t.wide_nodes else 'false'}, {'true' if t.sphere_only else 'false'}>(rtk::KParams)")
+                f"{'true' if t.wide_nodes else 'false'}, {'true' if t.sphere_only else 'false'}, "
+                f"{'true' if t.primary_visibility else 'false'}>(rtk::KParams)")
 
     def trace_samples(self, cam, ijs):
         ijs = np.ascontiguousarray(ijs, dtype=np.int32).reshape(-1, 3)

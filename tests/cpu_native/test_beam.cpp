@@ -98,7 +98,7 @@ int main(int argc, char **argv) {
         rtp::RtiowOptions o;
         rtp::HostScene hs;
         rtp::build_rtiow_scene(o, hs);
-        check_frame(hs, camera(1920, 1080, 20.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 37, spp, 15, "S-rtiow 1920x1080");
+        check_frame(hs, camera(1920, 1080, 20.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 17, spp, 15, "S-rtiow 1920x1080");
         check_frame(hs, camera(96, 64, 20.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 3, spp, 15, "S-rtiow 96x64 (fat pixels)");
         check_frame(hs, camera(320, 200, 60.0f, rtp::Vec3(0.3f, 0.2f, 0.12f), rtp::Vec3(4, 0, 0.2f)), 7, spp, 15, "S-rtiow, camera between the spheres");
         check_frame(hs, camera(16, 9, 90.0f, rtp::Vec3(13, 3, 2), rtp::Vec3(0, 0, 0)), 1, spp, 15, "S-rtiow 16x9 (many pixels without a list)");

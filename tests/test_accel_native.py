@@ -38,3 +38,20 @@ def test_margin_budget_against_adversarial_rays(tmp_path):
     hits, phantom, used = int(m.group(1)), int(m.group(2)), float(m.group(3))
     assert hits > 200000 and phantom > 10000          # the cancellation cases are really being produced
     assert 4.0 < used < 24.0
+
+
+def test_primary_ray_candidate_lists_hold_every_hit(tmp_path):
+    """csrc/rt_beam.h (the per-pixel candidate lists of the primary-visibility pass) against the oracle: for pixels of six
+    frames — the headline frame, fat pixels, a camera between the spheres, the config scene (planes), distance-aware margins —
+    every sphere whose hit_sphere can report a hit for any sampled camera ray of the pixel, and the oracle's closest hit, is
+    on the pixel's list (or the pixel has none)."""
+    exe = str(tmp_path / "test_beam")
+    srcs = [os.path.join(ROOT, "tests", "cpu_native", "test_beam.cpp"), os.path.join(PKG, "csrc", "rt_accel.cpp")]
+    srcs += [os.path.join(PKG, "host", f) for f in ("bvh_builder.cpp", "scene_params.cpp", "scene_builder.cpp", "texture_io.cpp",
+                                                    "jpeg_decoder.cpp", "png_writer.cpp", "camera.cpp")]
+    obj = str(tmp_path / "rt_oracle.o")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-std=gnu11", "-w", "-c", "-o", obj, os.path.join(ROOT, "oracle", "rt_oracle.c")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", exe] + srcs + [obj, "-lpthread", "-lm"], check=True)
+    out = subprocess.run([exe, "8"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all ok" in out.stdout

@@ -108,6 +108,76 @@ def test_rtiow_c2_rows_at_full_width(rtiow):
         assert_same_frame(fb[row0:row0 + 20], want, f"rows {row0}..")
 
 
+def test_production_kernel_at_the_headline_config():
+    """BASELINE configs[2] — 1920x1080, 500 spp, 50 bounces — through the DEFAULT path of a fresh handle: ONE launch of the
+    sphere-only trace kernel fed by the primary-visibility pass (render_kernel, src/camera.cu:17-34), three rows of the frame
+    compared bit for bit with the oracle."""
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    cam = rb.rtiow_camera(1920, 1080, 500, 50)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.sphere_only == 1 and t.primary_visibility == 1 and t.trace_launches == 1 and t.scene_in_lds == 1
+    assert t.workgroup_size == 1024 and t.num_workgroups == 512
+    assert 0 < t.flagged_samples < 1e-3 * 1920 * 1080 * 500
+    for row in (3, 540, 1073):        # sky, the big spheres, the foreground
+        want = ob.render(host, cam, row0=row, row1=row + 1, threads=1)
+        assert_same_frame(fb[row:row + 1], want, f"headline frame, row {row}")
+    dev.close()
+
+
+def test_rtiow_c2_at_full_spp():
+    """BASELINE configs[1] at its full 1200x800 x 100 spp x 50 bounces through the default path; two rows against the oracle."""
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    cam = rb.rtiow_camera(1200, 800, 100, 50)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.sphere_only == 1 and t.primary_visibility == 1 and t.trace_launches == 1
+    for row in (420, 777):
+        want = ob.render(host, cam, row0=row, row1=row + 1, threads=1)
+        assert_same_frame(fb[row:row + 1], want, f"C2 frame, row {row}")
+    dev.close()
+
+
+def test_primary_visibility_pass_changes_nothing_but_the_time(config_scene):
+    """rt_config.primary_visibility: camera rays resolved from per-pixel candidate lists (rt_primary.hip.inc) or walked like every
+    other ray — the same frame bit for bit, on the sphere-only kernel, on the general kernel (planes: the config scene), with
+    passes shorter and longer than a wave (the pass per batch and the pass per pixel), with several passes per frame, on a
+    row shard, and where most pixels have no list at all (fat pixels: more candidates than a list holds)."""
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    cases = [(rb.rtiow_camera(160, 90, 9, 50), {}, None), (rb.rtiow_camera(96, 54, 200, 50), {}, None),
+             (rb.rtiow_camera(64, 36, 300, 50), {"pass_spp": 150}, None), (rb.rtiow_camera(64, 36, 200, 50), {"pass_spp": 64}, None),
+             (rb.rtiow_camera(128, 72, 130, 50), {}, rb.Shard(8, 3, 1)), (rb.make_camera(16, 9, 90.0, (13, 3, 2), (0, 0, 0), (0.7, 0.8, 1.0), 130, 50), {}, None),
+             (rb.make_camera(200, 120, 60.0, (0.3, 0.2, 0.12), (4, 0, 0.2), (0.7, 0.8, 1.0), 16, 50), {}, None)]
+    for cam, cfg, shard in cases:
+        dev.configure(primary_visibility=0, pass_spp=cfg.get("pass_spp", 0))
+        a, ta = dev.render_to_host(cam, shard)
+        dev.configure(primary_visibility=-1)
+        b, tb = dev.render_to_host(cam, shard)
+        assert ta.primary_visibility == 1 and tb.primary_visibility == 0 and ta.guarded == 1 and tb.guarded == 1
+        assert_same_frame(a, b, f"{cam.image_width}x{cam.image_height}x{cam.samples_per_pixel} {cfg}")
+    dev.configure(primary_visibility=0, pass_spp=0)
+    cam = rb.rtiow_camera(96, 54, 130, 50)
+    fb, t = dev.render_to_host(cam)
+    assert t.primary_visibility == 1
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "pixel pass against the oracle")
+    dev.close()
+    # planes, triangles, quads, emitters: the general kernel
+    hostc, devc = config_scene
+    eye = list(hostc.frame_camera(0).origin.e)
+    for spp in (9, 144):
+        cam = rb.make_camera(200, 112, 50.0, eye, (0.0, 0.0, 4.5), (0, 0, 0), spp, 10)
+        devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_GUARDED)
+        a, ta = devc.render_to_host(cam)
+        devc.configure(primary_visibility=-1)
+        b, tb = devc.render_to_host(cam)
+        devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_AUTO)
+        assert ta.primary_visibility == 1 and ta.sphere_only == 0 and tb.primary_visibility == 0
+        assert_same_frame(a, b, f"config scene {spp} spp")
+        if spp == 9:
+            assert_same_frame(a, ob.render(hostc, cam, threads=8), "config scene against the oracle")
+
+
 def test_samples_accumulate_in_order(rtiow):
     """Linearity-style property usable at any size: the 64-spp pixel sum is the in-order float sum
     of the 64 per-sample radiances (src/camera.cu:27-31)."""
@@ -417,6 +487,29 @@ def test_context_renders_sharded_frames_through_the_c_abi():
         assert len(ts) == parts
         assert_same_frame(fb.cpu().numpy(), want, f"{parts}-way shard of one GPU, bands of {band}")
         ctx.close()
+
+
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """The N > 1 path of bench.py with the REAL HIP render: `bench.py --gpus 2` as its own launcher, two ranks sharing this
+    box's one GPU, each rendering its interleaved row bands of the headline frame, the bands gathered over gloo (RCCL does not
+    admit one GPU twice) and the assembled frame compared with the oracle on two rows.  What it cannot show is the RCCL
+    transport itself — that needs two GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RTP_BENCH_BACKEND="gloo", RTP_BENCH_CHECK="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size_seen_by_collective"] == 2 and out["config"]["collective_backend"] == "gloo"
+    assert out["checked_rows"]["assembled_frame_bit_identical"] is True
+    assert out["roofline"]["per_rank"]["trace_ms"] > 0 and out["roofline"]["per_rank"]["gather_ms"] > 0
+    assert out["value"] > 0 and out["scaling"] == "strong"
 
 
 def test_distance_aware_margins():
