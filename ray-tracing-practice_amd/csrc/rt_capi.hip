@@ -751,11 +751,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
 
     HIP_TRY(hipMemsetAsync(sc->queue, 0, kQueueWords * 4, stream));
     const bool overlap = guarded && !wavefront && !use_queue && cfg.overlap_rework >= 0 && sc->aux_stream != nullptr && sc->dirty != nullptr;
-    // Primary visibility without a walk (rt_primary.hip.inc): the LDS-resident octant walk with static margins, and a camera
-    // inside the distance those margins were sized for (so that the far-origin test can never fire for a camera ray; the
-    // device compares in float: a hair of slack)
-    bool prim = guarded && !wavefront && !use_queue && !wide && !dyn && (RTP_OCTANT != 0) && fast.in_lds && cfg.primary_visibility >= 0 && sc->nodes != nullptr &&
-                P.max_depth < rtk::kMaxPrimDepth;
+    // Primary visibility without a walk (rt_primary.hip.inc): the pair-node walks of render_kernel — the LDS-resident octant walk
+    // with static margins, and the walk with distance-aware margins (LDS-resident or through L1/L2) — and a camera inside the
+    // distance static margins were sized for (so that the far-origin test can never fire for a camera ray; the device compares
+    // in float: a hair of slack)
+    bool prim = guarded && !wavefront && !use_queue && !wide && (dyn || ((RTP_OCTANT != 0) && fast.in_lds)) && cfg.primary_visibility >= 0 &&
+                sc->nodes != nullptr && P.max_depth < rtk::kMaxPrimDepth;
     if (prim && sc->guard.num_small > 0) {
         const double dx = (double)cam->origin.e[0] - sc->guard.center[0], dy = (double)cam->origin.e[1] - sc->guard.center[1], dz = (double)cam->origin.e[2] - sc->guard.center[2];
         if (!(dx * dx + dy * dy + dz * dz <= (double)sc->guard.d0_sq * (1.0 - 1e-5))) prim = false;
@@ -927,6 +928,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
                     else HIP_TRY(launch(rtk::render_kernel<false, false, true, true>, P, wgs, fast.lds_bytes));
                 } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, false, true>, P, wgs, fast.lds_bytes));
+            } else if (dyn && prim) {
+                if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true, false, false, true>, P, wgs, fast.lds_bytes));
+                else HIP_TRY(launch(rtk::render_kernel<false, false, true, false, false, true>, P, wgs, fast.lds_bytes));
             } else if (dyn) {
                 if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true>, P, wgs, fast.lds_bytes));

@@ -10,7 +10,7 @@ ds=rb.DeviceScene(hs,device=0)
 fb=torch.zeros((2160,3840,3),dtype=torch.float32,device='cuda:0')
 t0=time.time(); tm=ds.render(cam, fb.data_ptr()); dt=time.time()-t0
 ns=3840*2160*spp
-print('C5 frame: kernel_ms %.1f trace_ms %.1f launches %d  Msamples/s %.1f (wall %.1fs) lds %d in_lds %d guarded %d flagged %d (%.3f %%) reason %r'%(tm.kernel_ms,tm.trace_ms,tm.trace_launches,ns/tm.kernel_ms/1e3,dt,tm.lds_bytes,tm.scene_in_lds,tm.guarded,tm.flagged_samples,100.0*tm.flagged_samples/ns,ds.guard_reason()))
+print('C5 frame: kernel_ms %.1f trace_ms %.1f launches %d  Msamples/s %.1f (wall %.1fs) lds %d in_lds %d guarded %d flagged %d (%.3f %%) reason %r primary %d (%.1f ms) rework %.1f ms'%(tm.kernel_ms,tm.trace_ms,tm.trace_launches,ns/tm.kernel_ms/1e3,dt,tm.lds_bytes,tm.scene_in_lds,tm.guarded,tm.flagged_samples,100.0*tm.flagged_samples/ns,ds.guard_reason(),tm.primary_visibility,tm.primary_ms,tm.rework_ms))
 got=fb.cpu().numpy()
 row=1500
 if spp<=16:

@@ -36,6 +36,6 @@ for r0 in range(0,H,60):
     bad+=int((~eq).sum()); maxabs=max(maxabs,float(np.abs(want-g).max()))
     print('rows',r0,'bad so far',bad,'elapsed %.0fs'%(time.time()-t), flush=True)
 res={'config':label,'pixels':W*H,'samples':W*H*SPP,'pixels_differing':bad,'max_abs_diff':maxabs,
-     'gpu_kernel_ms':tm.kernel_ms,'guarded_walk':int(tm.guarded),'guard_unproven':int(tm.guard_unproven),'trace_launches':int(tm.trace_launches),'flagged_samples':int(tm.flagged_samples),'oracle_seconds':time.time()-t,'frame_sha256':hashlib.sha256(got.tobytes()).hexdigest()}
+     'gpu_kernel_ms':tm.kernel_ms,'guarded_walk':int(tm.guarded),'guard_unproven':int(tm.guard_unproven),'trace_launches':int(tm.trace_launches),'primary_visibility':int(tm.primary_visibility),'sphere_only':int(tm.sphere_only),'guard_dynamic':int(tm.guard_dynamic),'flagged_samples':int(tm.flagged_samples),'oracle_seconds':time.time()-t,'frame_sha256':hashlib.sha256(got.tobytes()).hexdigest()}
 print(json.dumps(res))
 json.dump(res,open('gpurun_out/full_frame_parity_%s%s.json'%(os.environ.get('SCENE','rtiow'),'' if os.environ.get('VIEW','headline')=='headline' else '_'+os.environ['VIEW']),'w'),indent=1)
