@@ -39,7 +39,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracing-practice_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 500, 50
+WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 500, 50          # the headline workload; set_workload() switches the module to another one
+WORKLOAD = "headline"
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    "headline": dict(width=1920, height=1080, spp=500, half_extent=11, textured_quad=False, texture_size=0,
+                     text="S-rtiow random-sphere scene (486 spheres, 971 BVH nodes, seed 12345)"),
+    # BASELINE.json configs[4]: the stress scene (a secondary line, `--workload c5`; not what the driver runs)
+    "c5": dict(width=3840, height=2160, spp=1000, half_extent=158, textured_quad=True, texture_size=2048,
+               text="S-100k stress scene (99857 spheres + one textured METAL quad, 199715 BVH nodes, seed 12345)"),
+}
+
+
+def set_workload(name):
+    global WIDTH, HEIGHT, SPP, WORKLOAD
+    w = WORKLOADS[name]
+    WIDTH, HEIGHT, SPP, WORKLOAD = w["width"], w["height"], w["spp"], name
+
+
+def make_host_scene():
+    import rtp_bindings as rb
+    w = WORKLOADS[WORKLOAD]
+    if WORKLOAD == "headline":
+        return rb.HostScene.rtiow()
+    return rb.HostScene.rtiow(half_extent=w["half_extent"], textured_quad=w["textured_quad"], texture_size=w["texture_size"])
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-operations per second
 # (= the 157.3 TFLOPS fp32 vector peak at 2 flops per fused lane-op)
@@ -63,7 +86,7 @@ def _free_port():
 
 def _worker_cmd(args, extra=()):
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
-           "--warmup", str(args.warmup), "--spp", str(args.spp)]
+           "--warmup", str(args.warmup), "--spp", str(args.spp), "--workload", args.workload]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     if args.dry_run:
@@ -93,7 +116,7 @@ def _pmc_pass(args, counters, tag):
     # the program itself after `--`: the profiler's library has initialised the GPU before it starts
     cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
            sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "0",
-           "--spp", str(args.spp), "--no-cpu-baseline"]
+           "--spp", str(args.spp), "--workload", args.workload, "--no-cpu-baseline"]
     try:
         res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=args.pmc_timeout)
     except (subprocess.TimeoutExpired, OSError):
@@ -223,7 +246,7 @@ def host_threads():
     return max(1, min(16, n))
 
 
-def cpu_baseline(host, threads, budget_s=12.0, frame=None, gpu_cam=None):
+def cpu_baseline(host, threads, budget_s=12.0, frame=None, gpu_cam=None, dev=None):
     """The oracle (CPU restatement of the reference's render_cpu) on this box's host cores, on a
     bounded sample of the same workload: full 1920x1080 frame geometry, depth 50, reduced spp.
     Also returns the traversal statistics that price the algorithmic bytes per sample and, since
@@ -253,7 +276,14 @@ def cpu_baseline(host, threads, budget_s=12.0, frame=None, gpu_cam=None):
     checked = None
     if frame is not None and gpu_cam is not None:
         rows = [HEIGHT // 3, HEIGHT - 7]
-        checked = {"rows": rows, "gpu_frame_bit_identical": bool(all(
+        check_spp = gpu_cam.samples_per_pixel
+        if WORKLOAD != "headline" and dev is not None:
+            # the stress scene: a row at 1000 spp is 20 s of one host thread — the same scene handle renders the frame once
+            # more at 8 spp and two rows of THAT are compared
+            check_spp = 8
+            gpu_cam = rb.rtiow_camera(WIDTH, HEIGHT, check_spp, DEPTH)
+            frame, _ = dev.render_to_host(gpu_cam)
+        checked = {"rows": rows, "spp": check_spp, "gpu_frame_bit_identical": bool(all(
             np.array_equal(ob.render(host, gpu_cam, row0=r, row1=r + 1, threads=threads).view(np.uint32),
                            frame[r:r + 1].view(np.uint32)) for r in rows))}
     return {
@@ -331,7 +361,7 @@ def worker(args):
     torch.cuda.set_device(local_rank)
     rb._check(rb.amd_lib().rt_set_device(local_rank), "rt_set_device")
 
-    host = rb.HostScene.rtiow()
+    host = make_host_scene()
     cam = rb.rtiow_camera(WIDTH, HEIGHT, args.spp, DEPTH)
     dev = rb.DeviceScene(host)                      # scene resident in HBM before timing
     band = fp.DEFAULT_BAND_ROWS
@@ -416,7 +446,7 @@ def worker(args):
             "ms_per_step": round(ms_per_step, 3), "reference_equivalent_ms": round(ref_equiv_ms, 3) if ref_equiv_ms else None,
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S-rtiow random-sphere scene (486 spheres, 971 BVH nodes, seed 12345), {WIDTH}x{HEIGHT}, "
+            "config": {"workload": f"{WORKLOADS[WORKLOAD]['text']}, {WIDTH}x{HEIGHT}, "
                                    f"{args.spp} spp, {DEPTH} bounces, background (0.7,0.8,1.0)",
                        "parallelism": f"row-band shard x{world} + 1 gather" if world > 1 else "single GPU",
                        "collective_backend": (backend if world > 1 else None),
@@ -434,7 +464,7 @@ def worker(args):
                 np.array_equal(ob.render(host, cam, row0=r, row1=r + 1, threads=host_threads()).view(np.uint32),
                                got[r:r + 1].view(np.uint32)) for r in rows))}
         if world == 1 and not args.no_cpu_baseline:
-            base, st = cpu_baseline(host, host_threads(), frame=frame.detach().cpu().numpy(), gpu_cam=cam)
+            base, st = cpu_baseline(host, host_threads(), frame=frame.detach().cpu().numpy(), gpu_cam=cam, dev=dev)
             out["cpu_baseline"] = base
         # ---- roofline of the dominant kernel (the trace launch) ------------------------------------
         # The path is VALU-bound (scene tables live in LDS); the launcher adds the measured VALU issue x lane
@@ -493,7 +523,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (invalidates the headline)")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline",
+                    help="headline = BASELINE configs[2] (the metric's configuration, what the driver runs); c5 = BASELINE configs[4], a secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="launcher, N = 1: skip the rocprofv3 counter passes")
     ap.add_argument("--pmc-timeout", type=int, default=240)
@@ -502,6 +534,9 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    set_workload(args.workload)
+    if args.spp <= 0:
+        args.spp = SPP
     if "WORLD_SIZE" in os.environ:
         worker(args)
         return 0
