@@ -182,7 +182,9 @@ typedef struct rt_config {
     int32_t  kernel;              /* RT_KERNEL_*: AUTO picks per scene */
     uint64_t workspace_bytes;     /* budget of the per-pass sample workspace the scene handle owns (12 bytes per sample of a
                                      pass, allocated on demand).  0 = default: a sixteenth of the device's memory.  A smaller
-                                     budget means more, shorter passes: 4 GiB costs 1.9 % at 1920x1080x500 spp */
+                                     budget means more, shorter passes: 4 GiB costs 1.9 % at 1920x1080x500 spp.  Footprint: rows are
+                                     padded to 32 samples (128-byte lines; to 4 samples for passes shorter than 32), so a pass of S
+                                     samples per pixel takes pixels x round_up(S, 32) x 12 bytes */
     int32_t  pass_spp;            /* samples per pixel per pass (0 = auto: what the workspace admits) */
     int32_t  stack_levels;        /* cap on the guarded walk's per-lane stack entries (0 = auto) */
     uint32_t flag_capacity;       /* cap on the flagged-sample list (0 = auto; overflow = "re-walk everything") */
@@ -314,7 +316,12 @@ const char *rt_context_transport(const rt_context *ctx);
 /* rt_scene_create_ex on every device of the context (replaces the context's previous scene). */
 rt_status rt_context_scene_create(rt_context *ctx, const rt_scene_desc *desc, const rt_config *cfg);
 /* Camera::render for the whole node: d_fb_sum_root is image_height*image_width*3 floats on the ROOT device; returns
- * when the assembled frame is there.  band_rows <= 0: 8.  timings: NULL or num_devices entries (per-device rt_timing). */
+ * when the assembled frame is there.  band_rows <= 0: 8.  timings: NULL or num_devices entries (per-device rt_timing).
+ * Stream contract: the context works on non-blocking streams of its own.  rt_render_sharded and rt_gather drain the root
+ * device (hipDeviceSynchronize) before they write d_fb_sum_root, so work the caller queued on that buffer earlier, on any
+ * stream, is complete by then; they return after their own writes are complete.  The caller must not use the buffer from
+ * another thread during the call.  With more than one device the RCCL transport has run on real hardware only as a
+ * one-device self-gather so far. */
 rt_status rt_render_sharded(rt_context *ctx, const rt_camera_data *cam, int32_t band_rows, float *d_fb_sum_root,
                             rt_timing *timings);
 /* The collective alone: assembles the rows the devices hold from the last rt_render_sharded of this geometry. */

@@ -656,7 +656,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     // the pass grows N-fold, so a launch keeps the size it has on one GPU.
     const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
     int pass_size = P.spp;
-    auto pitch_of = [](int pass) { return (uint32_t)((pass + 31) & ~31); };     // rows of the slab start on 128-byte lines (32 x 12 B = 3 lines)
+    // rows of the slab start on 128-byte lines (32 slots x 12 B = 3 lines) — except for passes shorter than that, whose rows are
+    // only padded to the 16 bytes the accumulate kernel's row reads need (a 4K frame at 1 spp: 0.4 GB instead of 3.2 GB)
+    auto pitch_of = [](int pass) { return pass < 32 ? (uint32_t)((pass + 3) & ~3) : (uint32_t)((pass + 31) & ~31); };
     {
         const uint64_t budget = cfg.workspace_bytes ? cfg.workspace_bytes : sc->device_bytes / kWorkspaceShareOfDevice;
         uint64_t fit = budget / ((uint64_t)num_pixels * kSampleBytes);
@@ -750,7 +752,17 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     int wgs = grid_for(main_shape);
 
     HIP_TRY(hipMemsetAsync(sc->queue, 0, kQueueWords * 4, stream));
-    const bool overlap = guarded && !wavefront && !use_queue && cfg.overlap_rework >= 0 && sc->aux_stream != nullptr && sc->dirty != nullptr;
+    // (not with a capped flag list or an unproven margin: a list that overflowed makes the re-walk rewrite EVERY slab entry
+    // while the other stream sums the rows of unflagged pixels — harmless only where both walks give the same bits)
+    const bool overlap = guarded && !wavefront && !use_queue && cfg.overlap_rework >= 0 && sc->aux_stream != nullptr && sc->dirty != nullptr &&
+                         cfg.flag_capacity == 0 && !gamma_unproven(cfg);
+    // an early return between the fork to the second stream and the join must not leave that stream running unobserved
+    struct JoinOnExit {
+        rt_scene *sc; hipStream_t stream; bool forked = false;
+        ~JoinOnExit() {
+            if (forked && hipEventRecord(sc->ev_join, sc->aux_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, sc->ev_join, 0);
+        }
+    } join_guard{sc, stream};
     // Primary visibility without a walk (rt_primary.hip.inc): the pair-node walks of render_kernel — the LDS-resident octant walk
     // with static margins, and the walk with distance-aware margins (LDS-resident or through L1/L2) — and a camera inside the
     // distance static margins were sized for (so that the far-origin test can never fire for a camera ray; the device compares
@@ -955,6 +967,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
                 // the re-walk and the accumulation of the pixels it touches on the second stream …
                 HIP_TRY(hipEventRecord(sc->ev_fork, stream));
                 HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_fork, 0));
+                join_guard.forked = true;
                 launch_stream = sc->aux_stream;
             }
             HIP_TRY(launch_exact(R, grid_for(exact)));
@@ -978,6 +991,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
                                P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join, 0));
+            join_guard.forked = false;
         } else {
             hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
                                P.pass_count, pass == 0 ? 1 : 0, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);

@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
-#include <unistd.h>
 
 #include <cstdio>
 #include <cstring>
@@ -172,15 +171,10 @@ rt_status rt_context_create(int32_t num_devices, const int32_t *device_ordinals,
         ctx->transport = "copy";
     } else if (r.ok) {
         ctx->comms.assign(n, nullptr);
-        // This RCCL build prints a version banner on stdout when the first communicator is made.  stdout is the host
-        // program's data channel (the reference's drivers print their per-frame TSV there, src/camera.cu:346), so the
-        // banner is sent to stderr: fd 1 points at fd 2 for the duration of the call.
-        fflush(stdout);
-        const int saved_stdout = dup(1);
-        if (saved_stdout >= 0) (void)dup2(2, 1);
+        // (This RCCL build prints a version banner on stdout when the first communicator is made.  A library does not touch
+        // the process's file descriptors: a host whose stdout is a data channel — the CLI mirror prints the reference's
+        // per-frame TSV there — redirects around this call itself, before it starts any thread: host/render_driver.cpp.)
         const ncclResult_t rc = r.CommInitAll(ctx->comms.data(), (int)n, ctx->devices.data());
-        fflush(stdout);
-        if (saved_stdout >= 0) { (void)dup2(saved_stdout, 1); (void)close(saved_stdout); }
         if (rc != 0) {
             ctx->comms.clear();
             if (n > 1) return bail(mfail(RT_ERR_HIP, std::string("ncclCommInitAll: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error")));
@@ -238,8 +232,13 @@ rt_status rt_gather(rt_context *ctx, int32_t image_width, int32_t image_height, 
         rows[(size_t)r] = rt_shard_rows(image_height, n > 1 ? &sh : nullptr);
         if ((size_t)rows[(size_t)r] * image_width * 3 > ctx->local_floats[(size_t)r]) return mfail(RT_ERR_INVALID_ARG, "rt_gather before rt_render_sharded of this geometry");
     }
-    // the root's receive buffers
+    // Ordering against the caller's own work on d_fb_sum_root: the context's streams are non-blocking streams of its own, so
+    // nothing the caller queued on that buffer (a memset on its stream, say) is ordered before the writes below by itself.
+    // The root device is drained first — the frame takes tens of milliseconds, this costs microseconds.  (Contract, see
+    // include/rtp_amd.h: the caller must not touch d_fb_sum_root from another thread during the call.)
     MHIP(hipSetDevice(ctx->devices[0]));
+    MHIP(hipDeviceSynchronize());
+    // the root's receive buffers
     const bool via_rccl = !ctx->comms.empty();
     const bool via_copy = !via_rccl && n > 1;
     for (int r = (via_rccl || via_copy) ? 0 : 1; r < n; ++r) {
@@ -251,13 +250,22 @@ rt_status rt_gather(rt_context *ctx, int32_t image_width, int32_t image_height, 
     if (via_rccl) {
         Rccl &rc = rccl();
         MNCCL(rc.GroupStart());
-        for (int r = 0; r < n; ++r) {
+        // (a failing call inside the group must not leave the group open: it is closed before the error is returned)
+        ncclResult_t bad = 0;
+        const char *what = "";
+        for (int r = 0; r < n && bad == 0; ++r) {
             const size_t count = (size_t)rows[(size_t)r] * image_width * 3;
             if (count == 0) continue;
-            MNCCL(rc.Recv(ctx->staging[(size_t)r], count, kNcclFloat32, r, ctx->comms[0], ctx->streams[0]));
-            MNCCL(rc.Send(ctx->local_rows[(size_t)r], count, kNcclFloat32, 0, ctx->comms[(size_t)r], ctx->streams[(size_t)r]));
+            bad = rc.Recv(ctx->staging[(size_t)r], count, kNcclFloat32, r, ctx->comms[0], ctx->streams[0]);
+            what = "ncclRecv";
+            if (bad == 0) {
+                bad = rc.Send(ctx->local_rows[(size_t)r], count, kNcclFloat32, 0, ctx->comms[(size_t)r], ctx->streams[(size_t)r]);
+                what = "ncclSend";
+            }
         }
-        MNCCL(rc.GroupEnd());
+        const ncclResult_t ended = rc.GroupEnd();
+        if (bad != 0) return mfail(RT_ERR_HIP, std::string(what) + ": " + (rc.GetErrorString ? rc.GetErrorString(bad) : "RCCL error"));
+        MNCCL(ended);
     }
     if (via_copy)
         for (int r = 0; r < n; ++r) {

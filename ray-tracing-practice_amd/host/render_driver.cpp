@@ -11,6 +11,8 @@
 #include <mutex>
 #include <thread>
 
+#include <unistd.h>
+
 #include "camera.h"
 #include "scene_params.h"
 
@@ -185,7 +187,19 @@ void gpu_render_pipelined(const SceneParams &params, const rt_scene_desc &desc, 
 // the saver arithmetic on the device and the file is written while the next frame renders.  Same files, byte for byte.
 void gpu_render_sharded(const SceneParams &params, const rt_scene_desc &desc, int num_devices) {
     rt_context *ctx = nullptr;
-    RTP_CHECK(rt_context_create(num_devices, nullptr, &ctx));
+    {
+        // RCCL prints a version banner on stdout when the first communicator is made; stdout is this program's data channel
+        // (the per-frame TSV, src/camera.cu:346).  No other thread of this process exists yet, so fd 1 can point at fd 2 for
+        // the duration of the call — the application's business, not the library's.
+        std::cout.flush();
+        fflush(stdout);
+        const int saved_stdout = dup(1);
+        if (saved_stdout >= 0) (void)dup2(2, 1);
+        const rt_status st = rt_context_create(num_devices, nullptr, &ctx);
+        fflush(stdout);
+        if (saved_stdout >= 0) { (void)dup2(saved_stdout, 1); (void)close(saved_stdout); }
+        RTP_CHECK(st);
+    }
     RTP_CHECK(rt_context_scene_create(ctx, &desc, nullptr));
     const int n = rt_context_num_devices(ctx);
     const size_t num_pixels = static_cast<size_t>(params.width) * params.height;
