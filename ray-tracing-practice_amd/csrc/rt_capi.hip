@@ -15,9 +15,17 @@
 #include "rt_device_math.h"
 #include "rt_kernel.hip.inc"
 #include "rt_primary.hip.inc"
+// Developer build only (make dev → librtp_amd_dev.so, -DRTP_DEV_BUILD): the two experimental kernels that lost to render_kernel
+// (rt_kernel_wf.hip.inc: wave-owned path pools in L2, −37 %; rt_kernel_queue.hip.inc: T-wave/S-wave LDS queues, −30 %; docs/LOG.md) and
+// the rt_debug_* entry points (exhaustive on-device checks of recip / sqrt_cr / sphere_root, the RTP_STATS counters).  The shipped
+// library contains none of them.
+#ifdef RTP_DEV_BUILD
+#define RTP_DEV_QUEUE_KERNEL 1
 #include "rt_kernel_wf.hip.inc"
-#ifdef RTP_DEV_QUEUE_KERNEL      // developer build only (make DEV=1): the slower T-wave/S-wave LDS-queue experiment, DESIGN.md §5b
 #include "rt_kernel_queue.hip.inc"
+#else
+namespace rtk { constexpr int kWfBlock = 256, kWfRayRows = 0, kWfHitRows = 0; }
+#define RTP_WF_MIN_WAVES 4
 #endif
 
 namespace {
@@ -317,7 +325,19 @@ extern "C" {
 
 const char *rt_get_last_error_string(void) { return g_last_error.c_str(); }
 
-const char *rt_version_string(void) { return "rtp_amd 0.1 gfx950 parity=1"; }
+// parity: the arithmetic flags the bit-for-bit claims rest on (no contraction, IEEE divide / sqrt, denormals kept, no fast-math) —
+// the Makefile passes -DRTP_PARITY_FLAGS=1 together with them, and only with them; dev: the developer build (see above)
+#if defined(RTP_PARITY_FLAGS) && !defined(__FAST_MATH__)
+#define RTP_VERSION_PARITY "1"
+#else
+#define RTP_VERSION_PARITY "0"
+#endif
+#ifdef RTP_DEV_BUILD
+#define RTP_VERSION_DEV "1"
+#else
+#define RTP_VERSION_DEV "0"
+#endif
+const char *rt_version_string(void) { return "rtp_amd 0.3 gfx950 parity=" RTP_VERSION_PARITY " dev=" RTP_VERSION_DEV; }
 
 rt_status rt_set_device(int32_t device_ordinal) {
     int n = 0;
@@ -552,6 +572,9 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     Shape fast{};
     // kernel form of the guarded pass: render_kernel (a lane owns a path) or render_kernel_wf (a wave owns a pool of paths)
     const bool want_wavefront = cfg.kernel == RT_KERNEL_WAVEFRONT;
+#ifndef RTP_DEV_BUILD
+    if (want_wavefront) return fail(RT_ERR_UNSUPPORTED, "RT_KERNEL_WAVEFRONT is an experiment of the developer build (make dev): not in this library");
+#endif
     // 4-wide nodes where the scene has them (host-built tree with at least one inner node) and the configuration does not
     // ask for the pair nodes; the wavefront kernel walks pairs
     const bool wide = sc->wnodes != nullptr && sc->num_wide > 0 && cfg.wide_nodes != 0 && !want_wavefront;
@@ -932,8 +955,12 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
                 P.wf_pool = sc->wf_pool;
                 P.wf_cap = P.wf_target = wf_target;
                 P.wf_k_exchange = cfg.wavefront_exchange > 0 ? (cfg.wavefront_exchange > 64 ? 64 : cfg.wavefront_exchange) : 16;
+#ifdef RTP_DEV_BUILD
                 if (fast.in_lds) HIP_TRY(launch_wf(rtk::render_kernel_wf<true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch_wf(rtk::render_kernel_wf<false>, P, wgs, fast.lds_bytes));
+#else
+                (void)launch_wf;
+#endif
             } else if (wide) {
                 if (dyn) {
                     if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true, true>, P, wgs, fast.lds_bytes));
@@ -1071,6 +1098,7 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
     return RT_OK;
 }
 
+#ifdef RTP_DEV_BUILD
 // Developer hook (not part of the ABI header): the proof by exhaustion behind rt_device_math.h's recip() and sqrt_cr().
 // Runs every one of the 2^32 binary32 bit patterns through them on the current device and counts the inputs whose result
 // differs in any bit from the compiler's correctly rounded 1.0f / x and sqrtf(x) (NaN results count as equal to NaN).
@@ -1151,6 +1179,8 @@ rt_status rt_debug_read_stats(rt_scene *sc, uint32_t out[16]) {
     HIP_TRY(hipMemcpy(out, sc->queue + kQueueStats, 60, hipMemcpyDeviceToHost));
     return RT_OK;
 }
+
+#endif      // RTP_DEV_BUILD
 
 rt_status rt_last_kernel_ms(rt_scene *sc, float *ms) {
     if (!sc || !ms) return fail(RT_ERR_INVALID_ARG, "null argument");

@@ -40,7 +40,7 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session", autouse=True)
 def built_libraries():
     """Make sure the in-tree libraries exist (they are git-ignored build products)."""
-    needed = [os.path.join(PKG, "librtp_amd.so"), os.path.join(PKG, "librtp_host.so"),
+    needed = [os.path.join(PKG, "librtp_amd.so"), os.path.join(PKG, "librtp_amd_dev.so"), os.path.join(PKG, "librtp_host.so"),
               os.path.join(ROOT, "oracle", "librt_oracle.so")]
     if not all(os.path.exists(p) for p in needed):
         import __graft_entry__

@@ -1,0 +1,99 @@
+"""Checks that need the DEVELOPER build of the render library (librtp_amd_dev.so, `make -C ray-tracing-practice_amd dev`):
+the experimental wavefront kernel and the rt_debug_* entry points.  Not collected by the normal test run (the file name does
+not match test_*.py): tests/test_gpu_parity.py::test_developer_build_checks runs it in one child process with RTP_AMD_LIB
+pointing at the developer library."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bindings as ob
+import rtp_bindings as rb
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same_frame(got, want, what):
+    same = (bits(got) == bits(want)).all(axis=-1)
+    assert same.all(), f"{what}: {(~same).sum()} of {same.size} pixels differ, max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.fixture(scope="module")
+def config_scene(test_config_text):
+    host = rb.HostScene.from_config(test_config_text)
+    return host, rb.DeviceScene(host, device=0)
+
+
+def test_this_is_the_developer_library():
+    v = rb.amd_lib().rt_version_string()
+    assert b"dev=1" in v and b"parity=1" in v
+
+
+def test_wavefront_kernel_gives_the_same_frames():
+    """rt_config.kernel = RT_KERNEL_WAVEFRONT (rt_kernel_wf.hip.inc: a wave owns a pool of paths in wave-private L2-resident
+    stacks and alternates dense SHADE / GENERATE / EXCHANGE / TRACE steps) — same bits as the oracle: S-rtiow at several
+    pool sizes and exchange thresholds, a frame smaller than one wave's pool, the config scene (planes, lights,
+    absorbing glass), a far camera (far-origin flags) and a 2-entry traversal stack (many flagged samples)."""
+    host = rb.HostScene.rtiow()
+    cam = rb.rtiow_camera(200, 120, 12, 50)
+    want = ob.render(host, cam, threads=8)
+    for paths, exch in ((0, 0), (128, 4), (512, 32), (192, 64)):
+        dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT, wavefront_paths=paths, wavefront_exchange=exch)
+        fb, t = dev.render_to_host(cam)
+        assert t.kernel == rb.KERNEL_WAVEFRONT and t.guarded == 1
+        assert_same_frame(fb, want, f"wavefront kernel, pool {paths}, exchange {exch}")
+    dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT)
+    tiny = rb.rtiow_camera(7, 5, 3, 50)
+    fb, t = dev.render_to_host(tiny)
+    assert_same_frame(fb, ob.render(host, tiny, threads=4), "wavefront kernel, 105 samples in all")
+    far = rb.make_camera(160, 90, 3.0, (400.0, 90.0, 60.0), (0, 0, 0), (0.7, 0.8, 1.0), 4, 50)
+    dev.configure(guard_repack=0, stack_levels=2, guard_keep=1)
+    fb, t = dev.render_to_host(far)
+    assert t.kernel == rb.KERNEL_WAVEFRONT and t.flagged_samples > 1000
+    assert_same_frame(fb, ob.render(host, far, threads=8), "wavefront kernel, far camera, 2-entry stack")
+
+
+def test_wavefront_kernel_on_the_config_scene(config_scene):
+    host, _ = config_scene
+    dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
+    cam = host.frame_camera(0)
+    fb, t = dev.render_to_host(cam)
+    assert t.kernel == rb.KERNEL_WAVEFRONT and t.guarded == 1
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "wavefront kernel, config scene")
+
+
+def test_fast_reciprocal_and_sqrt_match_ieee_for_every_float():
+    """rt_device_math.h recip() / sqrt_cr(): a hardware estimate plus one fused correction inside an exponent fence, the
+    compiler's correctly rounded sequence outside it.  Proof by exhaustion on the device that renders: all 2^32 binary32
+    inputs, every result bit compared with 1.0f / x and sqrtf(x) (the reference's own operations, include/vec3.h:97,105)."""
+    import ctypes as C
+    lib = rb.amd_lib()
+    out = (C.c_uint64 * 3)()
+    lib.rt_debug_check_fast_math.argtypes = [C.POINTER(C.c_uint64)]
+    lib.rt_debug_check_fast_math.restype = C.c_int
+    assert lib.rt_debug_check_fast_math(out) == 0
+    assert out[2] == 2 ** 32
+    assert out[0] == 0, "recip() differs from 1.0f / x for %d inputs" % out[0]
+    assert out[1] == 0, "sqrt_cr() differs from sqrtf(x) for %d inputs" % out[1]
+
+
+def test_sphere_roots_from_one_reciprocal_match_the_plain_divisions():
+    """test_sphere's root selection (both fp64 quotients from one v_rcp_f64 + Newton steps, no scaling instructions) against
+    the reference's form with the compiler's correctly rounded divisions, on 2^32 SAMPLED operand sets (not an exhaustive proof: four
+    operands span 2^128 combinations): raw random bit patterns
+    (all exponents, inf, NaN, denormals) and scene-scale operands alike — same acceptance, same accepted root, bit for bit."""
+    import ctypes as C
+    lib = rb.amd_lib()
+    out = (C.c_uint64 * 3)()
+    lib.rt_debug_check_sphere_roots.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.rt_debug_check_sphere_roots.restype = C.c_int
+    assert lib.rt_debug_check_sphere_roots(2 ** 32, out) == 0
+    assert out[2] == 2 ** 32
+    assert out[1] > 2 ** 26          # accepted roots are really being produced and compared
+    assert out[0] == 0, "%d operand sets differ" % out[0]

@@ -432,39 +432,6 @@ def test_alternative_kernels_agree_with_default(rtiow):
         dev.configure(traversal=rb.TRAVERSAL_AUTO)
 
 
-def test_wavefront_kernel_gives_the_same_frames():
-    """rt_config.kernel = RT_KERNEL_WAVEFRONT (rt_kernel_wf.hip.inc: a wave owns a pool of paths in wave-private L2-resident
-    stacks and alternates dense SHADE / GENERATE / EXCHANGE / TRACE steps) — same bits as the oracle: S-rtiow at several
-    pool sizes and exchange thresholds, a frame smaller than one wave's pool, the config scene (planes, lights,
-    absorbing glass), a far camera (far-origin flags) and a 2-entry traversal stack (many flagged samples)."""
-    host = rb.HostScene.rtiow()
-    cam = rb.rtiow_camera(200, 120, 12, 50)
-    want = ob.render(host, cam, threads=8)
-    for paths, exch in ((0, 0), (128, 4), (512, 32), (192, 64)):
-        dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT, wavefront_paths=paths, wavefront_exchange=exch)
-        fb, t = dev.render_to_host(cam)
-        assert t.kernel == rb.KERNEL_WAVEFRONT and t.guarded == 1
-        assert_same_frame(fb, want, f"wavefront kernel, pool {paths}, exchange {exch}")
-    dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT)
-    tiny = rb.rtiow_camera(7, 5, 3, 50)
-    fb, t = dev.render_to_host(tiny)
-    assert_same_frame(fb, ob.render(host, tiny, threads=4), "wavefront kernel, 105 samples in all")
-    far = rb.make_camera(160, 90, 3.0, (400.0, 90.0, 60.0), (0, 0, 0), (0.7, 0.8, 1.0), 4, 50)
-    dev.configure(guard_repack=0, stack_levels=2, guard_keep=1)
-    fb, t = dev.render_to_host(far)
-    assert t.kernel == rb.KERNEL_WAVEFRONT and t.flagged_samples > 1000
-    assert_same_frame(fb, ob.render(host, far, threads=8), "wavefront kernel, far camera, 2-entry stack")
-
-
-def test_wavefront_kernel_on_the_config_scene(config_scene):
-    host, _ = config_scene
-    dev = rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
-    cam = host.frame_camera(0)
-    fb, t = dev.render_to_host(cam)
-    assert t.kernel == rb.KERNEL_WAVEFRONT and t.guarded == 1
-    assert_same_frame(fb, ob.render(host, cam, threads=8), "wavefront kernel, config scene")
-
-
 def test_context_renders_sharded_frames_through_the_c_abi():
     """rt_context / rt_render_sharded / rt_gather: (a) a one-device context — the gather runs through RCCL
     (ncclSend/ncclRecv to itself: the code path of an 8-GPU node, transport "rccl") and the frame is the oracle's;
@@ -1016,33 +983,24 @@ def test_hit_scene_on_crafted_rays():
     assert np.array_equal(t[h].view(np.uint32), ot[h].view(np.uint32)) and np.array_equal(prim[h], oprim[h])
 
 
-@pytest.mark.gpu
-def test_fast_reciprocal_and_sqrt_match_ieee_for_every_float():
-    """rt_device_math.h recip() / sqrt_cr(): a hardware estimate plus one fused correction inside an exponent fence, the
-    compiler's correctly rounded sequence outside it.  Proof by exhaustion on the device that renders: all 2^32 binary32
-    inputs, every result bit compared with 1.0f / x and sqrtf(x) (the reference's own operations, include/vec3.h:97,105)."""
-    import ctypes as C
+def test_developer_build_checks():
+    """The developer build (make dev → librtp_amd_dev.so: the shipped library plus the experimental wavefront kernel and the
+    rt_debug_* entry points) through tests/dev_build_checks.py, in ONE child process that loads that library instead of the
+    shipped one: recip() / sqrt_cr() against the compiler's correctly rounded forms on all 2^32 floats ON THIS DEVICE, the
+    shared-reciprocal sphere roots on 2^32 sampled operand sets, the wavefront kernel's frames against the oracle.  The
+    shipped library must not carry any of it."""
+    import subprocess
+    import sys
     lib = rb.amd_lib()
-    out = (C.c_uint64 * 3)()
-    lib.rt_debug_check_fast_math.argtypes = [C.POINTER(C.c_uint64)]
-    lib.rt_debug_check_fast_math.restype = C.c_int
-    assert lib.rt_debug_check_fast_math(out) == 0
-    assert out[2] == 2 ** 32
-    assert out[0] == 0, "recip() differs from 1.0f / x for %d inputs" % out[0]
-    assert out[1] == 0, "sqrt_cr() differs from sqrtf(x) for %d inputs" % out[1]
-
-
-@pytest.mark.gpu
-def test_sphere_roots_from_one_reciprocal_match_the_plain_divisions():
-    """test_sphere's root selection (both fp64 quotients from one v_rcp_f64 + Newton steps, no scaling instructions) against
-    the reference's form with the compiler's correctly rounded divisions, on 2^32 operand sets: raw random bit patterns
-    (all exponents, inf, NaN, denormals) and scene-scale operands alike — same acceptance, same accepted root, bit for bit."""
-    import ctypes as C
-    lib = rb.amd_lib()
-    out = (C.c_uint64 * 3)()
-    lib.rt_debug_check_sphere_roots.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
-    lib.rt_debug_check_sphere_roots.restype = C.c_int
-    assert lib.rt_debug_check_sphere_roots(2 ** 32, out) == 0
-    assert out[2] == 2 ** 32
-    assert out[1] > 2 ** 26          # accepted roots are really being produced and compared
-    assert out[0] == 0, "%d operand sets differ" % out[0]
+    assert b"dev=0" in lib.rt_version_string() and b"parity=1" in lib.rt_version_string()
+    assert not hasattr(lib, "rt_debug_check_fast_math") and not hasattr(lib, "rt_debug_check_sphere_roots")
+    host = rb.HostScene.rtiow()
+    with pytest.raises(RuntimeError, match="developer build"):
+        rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT).render_to_host(rb.rtiow_camera(32, 20, 2, 8))
+    dev_lib = os.path.join(os.path.dirname(HERE), "ray-tracing-practice_amd", "librtp_amd_dev.so")
+    assert os.path.exists(dev_lib), "run __graft_entry__.build() (make -C ray-tracing-practice_amd dev)"
+    env = dict(os.environ, RTP_AMD_LIB=dev_lib)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "dev_build_checks.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout
