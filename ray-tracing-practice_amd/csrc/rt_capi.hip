@@ -169,6 +169,7 @@ struct rt_scene {
     int num_cus = 0;
     uint64_t device_bytes = 0;      // total memory of the device (workspace default: a sixteenth of it)
     float build_ms = 0.0f;          // device BVH build time (RTP_BUILD=device), else 0
+    bool absorbing_glass = false;   // some DIELECTRIC material has a non-zero absorption (Beer-Lambert code needed)
 };
 
 namespace {
@@ -464,6 +465,10 @@ rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cf
     if ((st = upload(pk.leaf_boxes, (void **)&sc->leaf_boxes)) != RT_OK) return bail(st);
     if ((st = upload(pk.plane_leaf_boxes, (void **)&sc->plane_leaf_boxes)) != RT_OK) return bail(st);
     sc->guard = pk.guard;
+    for (int32_t m = 0; m < desc->num_materials; ++m) {
+        const rt_material &mat = desc->materials[m];
+        if (mat.type == RT_MAT_DIELECTRIC && !(mat.absorption.e[0] == 0.0f && mat.absorption.e[1] == 0.0f && mat.absorption.e[2] == 0.0f)) sc->absorbing_glass = true;
+    }
     if (pk.guard.ok) {
         sc->host_spheres.assign(desc->spheres, desc->spheres + desc->num_spheres);
         sc->host_planes.assign(desc->planes, desc->planes + desc->num_planes);
@@ -615,7 +620,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
         // sphere-only build: no planes, no textures, leaf boxes recomputed from the spheres; its LDS holds no material rows
         // (all three come from global memory), which pays for the wider stack rows of 1024 lanes
         simple = octant && cfg.scene_in_lds != 0 && cfg.sphere_only_kernel >= 0 && P.num_planes == 0 && sc->tex_data == nullptr &&
-                 P.leaf_boxes == nullptr && cfg.workgroups_per_cu == 0;
+                 P.leaf_boxes == nullptr && cfg.workgroups_per_cu == 0 && !sc->absorbing_glass;
         if (simple) {
             const uint64_t simple_bytes = ((uint64_t)P.num_internal * 5 + (uint64_t)P.num_spheres + ((uint64_t)P.num_spheres + 3) / 4) * 16;
             const uint64_t budget = kLdsLimit / 2;
@@ -951,6 +956,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             P.dirty_count = sc->queue + kQueueDirty + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
             if (const uint32_t tiny = cfg.flag_capacity) P.flag_cap = tiny < P.flag_cap ? tiny : P.flag_cap;   // test hook: overflow path
+            rtk::fill_consts(P);          // (everything the constants block copies is final now)
             if (wavefront) {
                 P.wf_pool = sc->wf_pool;
                 P.wf_cap = P.wf_target = wf_target;

@@ -400,9 +400,11 @@ RT_HD float pow5_rounded(float x) {
 // evaluating it: r0 + (1 - r0) * p is a non-decreasing function of p in float arithmetic (1 - r0 > 0, rounding is monotonic),
 // and the libm's p lies between the neighbours of the correctly rounded x^5.  If even the lower neighbour gives a value above
 // rnd the answer is yes, if not even the upper one does it is no; only when rnd falls inside that two-ulp window (~1e-7 of the
-// draws) is powf itself restated (pow5).  The glass branch runs in nine shade steps of ten; the table-driven pow5 cost 8 % of
-// the headline frame there.
-RT_HD bool schlick_exceeds(float cosine, float r0, float rnd) {
+// draws) is powf itself restated (pow5) — by the exact walk: the guarded trace kernel hands such a sample to the re-walk launch
+// like any other it cannot vouch for, so its hot shade step carries neither the table-driven code nor its registers (the glass
+// branch runs in nine shade steps of ten; evaluating pow5 there cost 8 % of the headline frame).
+// schlick_bracket: 1 = yes, 0 = no, -1 = rnd is inside the window (or the argument outside [0, 2]).
+RT_HD int schlick_bracket(float cosine, float r0, float rnd) {
     const float x = 1.0f - cosine;
     const float p = pow5_rounded(x);
     uint32_t pb;
@@ -414,8 +416,12 @@ RT_HD bool schlick_exceeds(float cosine, float r0, float rnd) {
     const float k = 1.0f - r0;
     const bool surely = (r0 + k * lo) > rnd;
     const bool maybe = (r0 + k * hi) > rnd;
-    if (surely == maybe && x >= 0.0f && x <= 2.0f) return surely;
-    return (r0 + k * pow5(x)) > rnd;
+    return (surely == maybe && x >= 0.0f && x <= 2.0f) ? (surely ? 1 : 0) : -1;
+}
+RT_HD bool schlick_exceeds(float cosine, float r0, float rnd) {
+    const int b = schlick_bracket(cosine, r0, rnd);
+    if (b >= 0) return b != 0;
+    return (r0 + (1.0f - r0) * pow5(1.0f - cosine)) > rnd;
 }
 RT_HD float reflectance(float cosine, float ref_idx) {     // include/materials.h:64-68
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
