@@ -1,6 +1,6 @@
 """Dev tool: kernel time of the rtiow frame under the env knobs given on the command line."""
 import os, sys, time
-sys.path.insert(0,'tests'); sys.path.insert(0,'ray-tracing-practice_amd')
+_R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,os.path.join(_R,'tests')); sys.path.insert(0,os.path.join(_R,'ray-tracing-practice_amd'))
 import rtp_bindings as rb, numpy as np
 W,H,SPP=int(os.environ.get('W',1920)),int(os.environ.get('H',1080)),int(os.environ.get('SPP',16))
 hs=rb.HostScene.rtiow(half_extent=int(os.environ.get('EXT',11)))
