@@ -388,28 +388,30 @@ RT_HD float schlick_r0sq(float ref_idx) {
     return r0 * r0;
 }
 RT_HD float reflectance_from_r0sq(float cosine, float r0) { return r0 + (1.0f - r0) * pow5(1.0f - cosine); }
-// x^5 correctly rounded (x^2 exact in double, two more roundings at 2^-53 — invisible after narrowing except on a float tie):
-// five instructions.  The host libm's powf(x, 5) is within ONE ulp of it for every float of [0, 2]
-// (tools/libm_exhaustive.cpp), which is all the next function needs.
-RT_HD float pow5_rounded(float x) {
-    const double d = (double)x;
-    const double d2 = d * d;
-    return (float)(d2 * d2 * d);
+// x^5 by three float multiplications: at most 4 x 2^-24 away from x^5 in relative terms, i.e. within 4 ulps of it (and within
+// one subnormal step where the result is subnormal); the host libm's powf(x, 5) is within 1.5 ulps of x^5.  So the libm's
+// value is never more than kPow5Window = 6 float steps away from this one — checked for every float of [0, 2]
+// (tools/libm_exhaustive.cpp: 0 of 1.07e9 beyond 6 steps, 65 k beyond 2), which is all the next function needs.
+RT_HD float pow5_float(float x) {
+    const float x2 = x * x;
+    return (x2 * x2) * x;
 }
+constexpr uint32_t kPow5Window = 6;
 // reflectance(cosine, ·) > rnd (include/materials.h:108), decided exactly as with the host libm's powf but without
 // evaluating it: r0 + (1 - r0) * p is a non-decreasing function of p in float arithmetic (1 - r0 > 0, rounding is monotonic),
-// and the libm's p lies between the neighbours of the correctly rounded x^5.  If even the lower neighbour gives a value above
-// rnd the answer is yes, if not even the upper one does it is no; only when rnd falls inside that two-ulp window (~1e-7 of the
+// and the libm's p lies within kPow5Window steps of pow5_float(x).  If even the lower end of that window gives a value above
+// rnd the answer is yes, if not even the upper end does it is no; only when rnd falls inside the window (~1e-6 of the
 // draws) is powf itself restated (pow5) — by the exact walk: the guarded trace kernel hands such a sample to the re-walk launch
-// like any other it cannot vouch for, so its hot shade step carries neither the table-driven code nor its registers (the glass
-// branch runs in nine shade steps of ten; evaluating pow5 there cost 8 % of the headline frame).
+// like any other it cannot vouch for, so its hot shade step carries neither the table-driven code nor its registers, nor any
+// double-precision temporaries (the glass branch runs in nine shade steps of ten; evaluating pow5 there cost 8 % of the
+// headline frame).
 // schlick_bracket: 1 = yes, 0 = no, -1 = rnd is inside the window (or the argument outside [0, 2]).
 RT_HD int schlick_bracket(float cosine, float r0, float rnd) {
     const float x = 1.0f - cosine;
-    const float p = pow5_rounded(x);
+    const float p = pow5_float(x);
     uint32_t pb;
     memcpy(&pb, &p, 4);
-    const uint32_t lb = p > 0.0f ? pb - 1u : pb, hb = pb + 1u;
+    const uint32_t lb = pb > kPow5Window ? pb - kPow5Window : 0u, hb = pb + kPow5Window;       // (x in [0, 2]: p >= 0, its bits are its rank)
     float lo, hi;
     memcpy(&lo, &lb, 4);
     memcpy(&hi, &hb, 4);

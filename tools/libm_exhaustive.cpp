@@ -36,8 +36,12 @@ int main() {
     sweep("expf, all floats of [-128, -0]", 0x80000000u, 0xC3000000u, [](uint32_t u) { const float x = bitsf(u); return !same(rtd::exp_libm(x), expf(x)); });
     sweep("expf, all floats of [0, 88]", 0u, 0x42B00000u, [](uint32_t u) { const float x = bitsf(u); return !same(rtd::exp_libm(x), expf(x)); });
     sweep("powf(x, 5), all floats of [0, 2]", 0u, 0x40000000u, [](uint32_t u) { const float x = bitsf(u); return !same(rtd::pow5(x), libm_powf(x, 5.0f)); });
-    sweep("powf(x, 5) farther than 1 ulp from rounded x^5", 0u, 0x40000000u, [](uint32_t u) { const float x = bitsf(u);
-        const int64_t d = (int64_t)fbits(rtd::pow5_rounded(x)) - (int64_t)fbits(libm_powf(x, 5.0f)); return d > 1 || d < -1; });
+    for (int w = 2; w <= 6; w += 4) {
+        char what[96];
+        std::snprintf(what, sizeof what, "powf(x, 5) more than %d steps from pow5_float(x)", w);
+        sweep(what, 0u, 0x40000000u, [w](uint32_t u) { const float x = bitsf(u);
+            const int64_t d = (int64_t)fbits(rtd::pow5_float(x)) - (int64_t)fbits(libm_powf(x, 5.0f)); return d > w || d < -w; });
+    }
     sweep("acosf, all floats of [-1, 1] (and NaN beyond)", 0u, 0xFFFFFFFFu, [](uint32_t u) { const float x = bitsf(u); return !same(rtd::acos_libm(x), acosf(x)); });
     sweep("atanf, all 2^32 floats", 0u, 0xFFFFFFFFu, [](uint32_t u) { const float x = bitsf(u); return !same(rtd::atan_libm(x), atanf(x)); });
     sweep("atan2f, 2^31 pairs (random bits / unit vectors)", 0u, 0x7FFFFFFFu, [](uint32_t u) {
