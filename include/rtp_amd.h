@@ -261,6 +261,12 @@ int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard);
 rt_status rt_render(rt_scene *scene, const rt_camera_data *cam, const rt_shard *shard,
                     float *d_fb_sum, void *hip_stream, int32_t sync, rt_timing *timing);
 
+/* The same for a RECTANGLE of the image (tile_x0, tile_y0, w, h): d_fb_sum is tile_h rows of tile_w pixels, row-major;
+ * pixel (x, y) of the tile is pixel (tile_x0 + x, tile_y0 + y) of the image — the same seeds, the same camera rays, the same
+ * sums, so tiles of any shape assemble to the bits of the whole frame.  RT_ERR_INVALID_ARG for a tile that leaves the image. */
+rt_status rt_render_tile(rt_scene *scene, const rt_camera_data *cam, int32_t tile_x0, int32_t tile_y0, int32_t tile_w, int32_t tile_h,
+                         float *d_fb_sum, void *hip_stream, int32_t sync, rt_timing *timing);
+
 /* Milliseconds of the most recent rt_render kernel of this scene (waits for it). */
 rt_status rt_last_kernel_ms(rt_scene *scene, float *ms);
 /* The whole rt_timing of the most recent rt_render of this scene (waits for it). */

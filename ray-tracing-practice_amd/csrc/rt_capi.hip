@@ -218,7 +218,8 @@ rt_status check_device(const rt_scene *sc) {
     return RT_OK;
 }
 
-rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, rtk::KParams &P) {
+struct Tile { int32_t x0, y0, w, h; };
+rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, rtk::KParams &P, const Tile *tile = nullptr) {
     std::memset(&P, 0, sizeof(P));
     if (!sc || !cam) return fail(RT_ERR_INVALID_ARG, "null scene or camera");
     if (cam->image_width <= 0 || cam->image_height <= 0) return fail(RT_ERR_INVALID_ARG, "image size must be positive");
@@ -239,6 +240,17 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.num_parts = s.num_parts;
     P.part = s.part;
     P.local_rows = rt_shard_rows(cam->image_height, shard);
+    P.row_w = P.width;
+    if (tile) {             // a rectangle of the image instead of row bands
+        if (shard && shard->num_parts > 1) return fail(RT_ERR_INVALID_ARG, "a tile and a shard in one call");
+        if (tile->w <= 0 || tile->h <= 0 || tile->x0 < 0 || tile->y0 < 0 || (int64_t)tile->x0 + tile->w > cam->image_width ||
+            (int64_t)tile->y0 + tile->h > cam->image_height)
+            return fail(RT_ERR_INVALID_ARG, "tile outside the image");
+        P.local_rows = tile->h;
+        P.row_w = tile->w;
+        P.tile_x0 = tile->x0;
+        P.tile_y0 = tile->y0;
+    }
     P.nodes = sc->nodes; P.hnodes = sc->hnodes; P.num_internal = sc->num_internal; P.root = sc->root;
     P.wnodes = sc->wnodes; P.whnodes = sc->whnodes; P.num_wide = sc->num_wide; P.wroot = sc->wroot;
     P.tnodes = sc->tnodes; P.num_tnodes = sc->num_tnodes;
@@ -249,12 +261,12 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.sphere_mat = sc->sphere_mat;
     P.tex_data = sc->tex_data; P.tex_info = sc->tex_info;
     P.queue = sc->queue;
-    if ((uint64_t)P.local_rows * (uint64_t)P.width > (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 pixels per call");
+    if ((uint64_t)P.local_rows * (uint64_t)P.row_w > (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 pixels per call");
     P.total_work = 0;      // set per pass in rt_render
     P.stats = sc->queue + kQueueStats;
     {
-        const uint64_t pixels = (uint64_t)P.local_rows * (uint64_t)P.width;
-        if (!make_magic((uint32_t)P.width, pixels + 1, P.magic_width) ||
+        const uint64_t pixels = (uint64_t)P.local_rows * (uint64_t)P.row_w;
+        if (!make_magic((uint32_t)P.row_w, pixels + 1, P.magic_width) ||
             !make_magic((uint32_t)P.band_rows, (uint64_t)P.local_rows + 1, P.magic_band))
             return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");
     }
@@ -526,10 +538,14 @@ int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard) {
     return (int32_t)rows;
 }
 
-rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, float *d_fb_sum, void *hip_stream,
-                    int32_t sync, rt_timing *timing) {
+}  // extern "C"
+
+namespace {
+// rt_render and rt_render_tile: whole rows of a shard, or a rectangle
+rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, const Tile *tile, float *d_fb_sum, void *hip_stream,
+                      int32_t sync, rt_timing *timing) {
     rtk::KParams P;
-    rt_status st = fill_params(sc, cam, shard, P);
+    rt_status st = fill_params(sc, cam, shard, P, tile);
     if (st != RT_OK) return st;
     if ((st = check_device(sc)) != RT_OK) return st;
     if (!d_fb_sum) return fail(RT_ERR_INVALID_ARG, "null framebuffer");
@@ -537,7 +553,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     hipStream_t stream = (hipStream_t)hip_stream;
     P.fb = d_fb_sum;
     if (timing) std::memset(timing, 0, sizeof(*timing));
-    const size_t fb_bytes = (size_t)P.local_rows * P.width * 3 * sizeof(float);
+    const size_t fb_bytes = (size_t)P.local_rows * P.row_w * 3 * sizeof(float);
     if (P.local_rows == 0) return RT_OK;
     if (P.spp <= 0 || P.max_depth <= 0) {     // the reference's loops add nothing: all-zero sums
         HIP_TRY(hipMemsetAsync(d_fb_sum, 0, fb_bytes, stream));
@@ -601,7 +617,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
             std::isfinite(cam->origin.e[2]) && cfg.guard_repack) {
             st = repack_for_camera(sc, cam->origin.e, stream);
             if (st != RT_OK) return st;
-            st = fill_params(sc, cam, shard, P);       // table pointers and guard parameters changed
+            st = fill_params(sc, cam, shard, P, tile);       // table pointers and guard parameters changed
             if (st != RT_OK) return st;
             P.fb = d_fb_sum;
         }
@@ -682,7 +698,7 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     // division; the passes of a frame are made equally long.
     // Fewer, larger launches amortise the end-of-launch tail — on a row shard of an N-GPU frame
     // the pass grows N-fold, so a launch keeps the size it has on one GPU.
-    const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.width;
+    const uint32_t num_pixels = (uint32_t)P.local_rows * (uint32_t)P.row_w;
     int pass_size = P.spp;
     // rows of the slab start on 128-byte lines (32 slots x 12 B = 3 lines) — except for passes shorter than that, whose rows are
     // only padded to the 16 bytes the accumulate kernel's row reads need (a 4K frame at 1 spp: 0.4 GB instead of 3.2 GB)
@@ -1057,6 +1073,20 @@ rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *sha
     if (sync) return rt_last_timing(sc, timing);
     if (timing) *timing = sc->last;
     return RT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+rt_status rt_render(rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, float *d_fb_sum, void *hip_stream,
+                    int32_t sync, rt_timing *timing) {
+    return render_impl(sc, cam, shard, nullptr, d_fb_sum, hip_stream, sync, timing);
+}
+
+rt_status rt_render_tile(rt_scene *sc, const rt_camera_data *cam, int32_t tile_x0, int32_t tile_y0, int32_t tile_w, int32_t tile_h,
+                         float *d_fb_sum, void *hip_stream, int32_t sync, rt_timing *timing) {
+    const Tile tile{tile_x0, tile_y0, tile_w, tile_h};
+    return render_impl(sc, cam, nullptr, &tile, d_fb_sum, hip_stream, sync, timing);
 }
 
 rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {

@@ -95,7 +95,7 @@ assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
 # Every symbol include/rtp_amd.h declares (tests check that the library exports all of them).
 RTP_AMD_SYMBOLS = [
     "rt_set_device", "rt_scene_create", "rt_scene_create_ex", "rt_config_init", "rt_config_from_env", "rt_scene_set_config",
-    "rt_scene_get_config", "rt_scene_destroy", "rt_scene_guard_reason", "rt_shard_rows", "rt_render", "rt_last_kernel_ms",
+    "rt_scene_get_config", "rt_scene_destroy", "rt_scene_guard_reason", "rt_shard_rows", "rt_render", "rt_render_tile", "rt_last_kernel_ms",
     "rt_last_timing",
     "rt_render_to_host", "rt_trace_samples", "rt_closest_hits", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
     "rt_get_last_error_string", "rt_version_string",
@@ -160,6 +160,8 @@ def amd_lib():
         lib.rt_shard_rows.restype = C.c_int32
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p, C.c_void_p,
                                   C.c_int32, C.POINTER(Timing)]
+        lib.rt_render_tile.argtypes = [C.c_void_p, C.POINTER(CameraData), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.POINTER(Timing)]
         lib.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         lib.rt_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         lib.rt_render_to_host.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p,
@@ -332,6 +334,21 @@ class DeviceScene:
         _check(amd_lib().rt_render(self._h, C.byref(cam), C.byref(shard) if shard else None, C.c_void_p(d_fb_ptr),
                                    C.c_void_p(stream or 0), 1 if sync else 0, C.byref(t)), "rt_render")
         return t
+
+    def render_tile_to_host(self, cam, x0, y0, w, h):
+        """rt_render_tile into a fresh device buffer, copied to the host: (h, w, 3) float32 sums and the rt_timing."""
+        lib = amd_lib()
+        d = C.c_void_p()
+        _check(lib.rt_device_alloc(max(w, 0) * max(h, 0) * 12 or 12, C.byref(d)), "rt_device_alloc")
+        t = Timing()
+        self._apply_config()
+        try:
+            _check(lib.rt_render_tile(self._h, C.byref(cam), x0, y0, w, h, d, C.c_void_p(0), 1, C.byref(t)), "rt_render_tile")
+            fb = np.empty((h, w, 3), dtype=np.float32)
+            _check(lib.rt_copy_to_host(fb.ctypes.data, d, fb.nbytes), "rt_copy_to_host")
+        finally:
+            lib.rt_device_free(d)
+        return fb, t
 
     def last_kernel_ms(self):
         ms = C.c_float()

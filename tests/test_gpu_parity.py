@@ -229,6 +229,34 @@ def test_sharded_render_equals_full_frame(rtiow):
         assert np.array_equal(bits(frame), bits(full))
 
 
+def test_tiles_of_any_shape_assemble_the_frame(rtiow, config_scene):
+    """rt_render_tile (tile_x0, tile_y0, w, h): rectangles rendered one by one — ragged sizes, a single pixel, a
+    single column — put together are the bits of the whole frame, with and without the primary-visibility pass, on the
+    sphere-only kernel, the general kernel (planes) and the exact walk; a rectangle that leaves the image is refused."""
+    for (host, dev), cam, cfg in ((rtiow, rb.rtiow_camera(97, 61, 130, 50), {}), (rtiow, rb.rtiow_camera(97, 61, 7, 50), {"primary_visibility": -1}),
+                                  (rtiow, rb.rtiow_camera(64, 40, 5, 50), {"traversal": rb.TRAVERSAL_EXACT}),
+                                  (config_scene, rb.make_camera(90, 50, 50.0, list(config_scene[0].frame_camera(0).origin.e), (0.0, 0.0, 4.5), (0, 0, 0), 9, 10),
+                                   {"traversal": rb.TRAVERSAL_GUARDED})):
+        dev.configure(**cfg)
+        W, H = cam.image_width, cam.image_height
+        whole, _ = dev.render_to_host(cam)
+        got = np.full_like(whole, np.nan)
+        xs = [0, 1, 34, W - 1, W]                  # columns [0,1) [1,34) [34,W-1) [W-1,W)
+        ys = [0, 17, 18, H]
+        for y0, y1 in zip(ys[:-1], ys[1:]):
+            for x0, x1 in zip(xs[:-1], xs[1:]):
+                tile, t = dev.render_tile_to_host(cam, x0, y0, x1 - x0, y1 - y0)
+                assert tile.shape == (y1 - y0, x1 - x0, 3)
+                got[y0:y1, x0:x1] = tile
+        assert_same_frame(got, whole, f"tiles of a {W}x{H} frame {cfg}")
+        dev.configure(**{k: 0 for k in cfg})
+    host, dev = rtiow
+    cam = rb.rtiow_camera(32, 20, 2, 8)
+    for bad in ((-1, 0, 4, 4), (30, 0, 4, 4), (0, 18, 4, 4), (0, 0, 0, 4)):
+        with pytest.raises(RuntimeError, match="tile"):
+            dev.render_tile_to_host(cam, *bad)
+
+
 def test_render_into_torch_buffer_on_a_stream(rtiow):
     import torch
     host, dev = rtiow

@@ -3,7 +3,7 @@
 #   gpurun --timeout 900 -- 'bash tools/profile_bench.sh r01'
 # Kernel trace and each PMC group are separate rocprofv3 runs (never --pmc together with tracing).
 set -eo pipefail
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"

@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -43,7 +43,8 @@ def means(name):
     for r in csv.DictReader(open(os.path.join(dst, f"pmc_{name}.csv"))):
         kn = r["Kernel_Name"]
         kind = ("trace" if MAIN.startswith(kn) or kn.startswith(MAIN) else "rework" if "render_kernel" in kn
-                else "accumulate_list" if "accumulate_kernel<true>" in kn else "accumulate" if "accumulate_kernel" in kn else None)
+                else "accumulate_list" if "accumulate_kernel<true>" in kn else "accumulate" if "accumulate_kernel" in kn
+                else "primary" if "primary_" in kn else "candidates" if "cand_kernel" in kn else None)
         if kind is None:
             continue
         key = (kind, r["Counter_Name"])
@@ -71,7 +72,15 @@ traffic = {
     "bytes_per_rework_launch": int((2 * f.get(("rework", "FETCH_SIZE"), 0) + w.get(("rework", "WRITE_SIZE"), 0)) * 1024),
     "bytes_per_accumulate_launch": int((2 * f[("accumulate", "FETCH_SIZE")] + w[("accumulate", "WRITE_SIZE")]) * 1024),
     "bytes_per_accumulate_list_launch": int((2 * f.get(("accumulate_list", "FETCH_SIZE"), 0.0) + w.get(("accumulate_list", "WRITE_SIZE"), 0.0)) * 1024),
+    "bytes_per_primary_launch": int((2 * f.get(("primary", "FETCH_SIZE"), 0.0) + w.get(("primary", "WRITE_SIZE"), 0.0)) * 1024),
+    "bytes_per_candidates_launch": int((2 * f.get(("candidates", "FETCH_SIZE"), 0.0) + w.get(("candidates", "WRITE_SIZE"), 0.0)) * 1024),
 }
+rows_bytes = bench["roofline"]["samples_per_launch"] * 12
+traffic["slab_rows_bytes_per_launch"] = rows_bytes
+traffic["trace_write_amplification"] = round(w[("trace", "WRITE_SIZE")] * 1024 / rows_bytes, 3)
+traffic["primary_write_amplification"] = round(w.get(("primary", "WRITE_SIZE"), 0.0) * 1024 / rows_bytes, 3)
+traffic["frame_total_bytes"] = sum(traffic[k] for k in ("bytes_per_trace_launch", "bytes_per_rework_launch", "bytes_per_accumulate_launch",
+                                                         "bytes_per_accumulate_list_launch", "bytes_per_primary_launch", "bytes_per_candidates_launch")) * int(launches and 1)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 
 v, _ = means("valu")
