@@ -273,21 +273,28 @@ def binary_image_bytes(fb_sum, width, height, divisor):
     return np.array([width, height], dtype=np.int32).tobytes() + quantize(fb_sum, divisor).tobytes()
 
 
+# Developer tools (tools/*.py) set HONOUR_ENV = True: handles made without an explicit honour_env then overlay the RTP_*
+# variables through rt_config_from_env().  Tests and bench.py leave it off: they configure through rt_config fields only.
+HONOUR_ENV = False
+# rt_config fields every DeviceScene made without them starts from (a test fixture's way to say "guarded walk throughout")
+DEFAULTS = {}
+
+
 class DeviceScene:
     """rt_scene handle (device-resident repacked scene).
 
     Configuration: keyword arguments are rt_config fields (e.g. traversal=rb.TRAVERSAL_EXACT, pass_spp=64,
     tree_build=rb.BUILD_DEVICE_LBVH); configure(**fields) changes the render-time ones later.  With
-    honour_env=True (the default of this TEST/TOOL binding, not of the library, which never reads the
+    honour_env=True (what developer tools ask for through rb.HONOUR_ENV; the library itself never reads the
     environment) the RTP_* developer variables are overlaid through rt_config_from_env() at creation and
     before every render, so a harness can flip a knob around a single call."""
 
-    def __init__(self, host_scene, device=None, honour_env=True, **config):
+    def __init__(self, host_scene, device=None, honour_env=None, **config):
         lib = amd_lib()
         if device is not None:
             _check(lib.rt_set_device(device), "rt_set_device")
         self._h = C.c_void_p()
-        self._honour_env = honour_env
+        self._honour_env = HONOUR_ENV if honour_env is None else honour_env
         self._explicit = dict(config)
         cfg = self._make_config()
         _check(lib.rt_scene_create_ex(C.byref(host_scene.desc), C.byref(cfg), C.byref(self._h)), "rt_scene_create_ex")
@@ -297,7 +304,7 @@ class DeviceScene:
         cfg = Config()
         amd_lib().rt_config_init(C.byref(cfg))
         assert cfg.struct_bytes == C.sizeof(Config), (cfg.struct_bytes, C.sizeof(Config))
-        for k, v in self._explicit.items():
+        for k, v in {**DEFAULTS, **self._explicit}.items():
             setattr(cfg, k, v)
         if self._honour_env:
             amd_lib().rt_config_from_env(C.byref(cfg))

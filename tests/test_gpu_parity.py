@@ -205,12 +205,12 @@ def test_pass_size_does_not_change_the_frame(rtiow):
     assert_same_frame(want[20:26], ob.render(host, cam, row0=20, row1=26, threads=8), "one pass of 150 spp")
     try:
         for forced, launches in ((64, 3), (100, 2), (7, 22)):
-            os.environ["RTP_PASS_SPP"] = str(forced)
+            dev.configure(pass_spp=forced)
             got, t = dev.render_to_host(cam)
             assert t.trace_launches == launches
             assert_same_frame(got, want, f"passes of {forced} spp")
     finally:
-        os.environ.pop("RTP_PASS_SPP", None)
+        dev.configure(pass_spp=0)
 
 
 def test_sharded_render_equals_full_frame(rtiow):
@@ -665,18 +665,17 @@ def test_guarded_walk_flags_and_rewalks(rtiow, force_guarded):
     rows = ob.render(host, cam, row0=100, row1=140, threads=8)
     assert_same_frame(fb[100:140], rows, "guarded walk")
     try:
-        os.environ["RTP_STACK_LEVELS"] = "2"
+        dev.configure(stack_levels=2)
         fb2, t2 = dev.render_to_host(cam)
         assert t2.guarded == 1 and t2.flagged_samples > 4 * t.flagged_samples
         assert_same_frame(fb2, fb, "2-entry stack")
         # a flagged-sample list that overflows its capacity makes the exact walk redo every sample
-        os.environ["RTP_FLAG_CAP"] = "1000"
+        dev.configure(flag_capacity=1000)
         fb3, t3 = dev.render_to_host(cam)
         assert t3.guarded == 1 and t3.flagged_samples > 1000
         assert_same_frame(fb3, fb, "overflowed flag list")
     finally:
-        os.environ.pop("RTP_STACK_LEVELS", None)
-        os.environ.pop("RTP_FLAG_CAP", None)
+        dev.configure(stack_levels=0, flag_capacity=0)
 
 
 def test_guarded_scene_handles_are_independent_and_reusable():
@@ -712,13 +711,11 @@ def test_guarded_walk_steps_aside_when_it_keeps_flagging(rtiow):
     dev = rb.DeviceScene(host, device=0)
     cam = rb.rtiow_camera(240, 135, 8, 50)
     want = ob.render(host, cam, threads=8)
-    try:
-        os.environ["RTP_STACK_LEVELS"] = "2"
-        fb, t = dev.render_to_host(cam)
-        assert t.guarded == 1 and t.flagged_samples * 50 > 240 * 135 * 8
-        assert_same_frame(fb, want, "heavily flagged frame")
-    finally:
-        os.environ.pop("RTP_STACK_LEVELS", None)
+    dev.configure(stack_levels=2)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.flagged_samples * 50 > 240 * 135 * 8
+    assert_same_frame(fb, want, "heavily flagged frame")
+    dev.configure(stack_levels=0)
     fb, t = dev.render_to_host(cam)
     assert t.guarded == 0 and t.flagged_samples == 0
     assert_same_frame(fb, want, "next frame, exact walk")
@@ -732,13 +729,11 @@ def test_guarded_walk_far_camera_and_ties(force_guarded):
     dev = rb.DeviceScene(host, device=0)
     cam = rb.make_camera(160, 90, 3.0, (400.0, 90.0, 60.0), (0, 0, 0), (0.7, 0.8, 1.0), 4, 50)
     want = ob.render(host, cam, threads=8)
-    try:
-        os.environ["RTP_NO_REPACK"] = "1"           # margins as packed: the far-origin test has to catch the primary rays
-        fb, t = dev.render_to_host(cam)
-        assert t.guarded == 1 and t.flagged_samples > 1000
-        assert_same_frame(fb, want, "far camera, far-origin test")
-    finally:
-        os.environ.pop("RTP_NO_REPACK", None)
+    dev.configure(guard_repack=0)                   # margins as packed: the far-origin test has to catch the primary rays
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.flagged_samples > 1000
+    assert_same_frame(fb, want, "far camera, far-origin test")
+    dev.configure(guard_repack=1)
     fb, t2 = dev.render_to_host(cam)                # default: the tree is re-packed with margins for this camera
     assert t2.guarded == 1 and t2.flagged_samples < t.flagged_samples // 4
     assert_same_frame(fb, want, "far camera, re-packed tree")
@@ -763,11 +758,11 @@ def test_guarded_walk_far_camera_and_ties(force_guarded):
 
 @pytest.fixture
 def force_guarded():
-    os.environ["RTP_TRAVERSAL"] = "guarded"
-    os.environ["RTP_GUARD_KEEP"] = "1"       # (a handle that flags > 2 % of a frame's samples would switch to the exact walk)
+    """rt_config for every handle the test makes or re-configures: guarded walk whatever the scene's size, and kept even
+    after a frame that flags more than 2 % of its samples (such a handle would otherwise switch to the exact walk)."""
+    rb.DEFAULTS.update(traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
     yield
-    os.environ.pop("RTP_TRAVERSAL", None)
-    os.environ.pop("RTP_GUARD_KEEP", None)
+    rb.DEFAULTS.clear()
 
 
 def test_guarded_walk_on_plane_scenes(config_scene, force_guarded):
@@ -793,11 +788,11 @@ def test_guarded_walk_on_plane_scenes(config_scene, force_guarded):
 
 
 def test_device_built_tree_gives_the_same_frames(force_guarded):
-    """RTP_BUILD=device: the guarded walk's tree is an LBVH built on the GPU (rt_build.hip).  Any tree
+    """rt_config.tree_build = RT_BUILD_DEVICE_LBVH: the guarded walk's tree is an LBVH built on the GPU (rt_build.hip).  Any tree
     over the inflated leaf boxes must give the oracle's frame: S-rtiow (one huge + 485 small
     spheres), mixed sphere/plane scenes, scenes of one and two primitives, equal Morton keys
     (coincident spheres)."""
-    os.environ["RTP_BUILD"] = "device"
+    rb.DEFAULTS.update(tree_build=rb.BUILD_DEVICE_LBVH)
     try:
         host = rb.HostScene.rtiow()
         dev = rb.DeviceScene(host, device=0)
@@ -825,7 +820,7 @@ def test_device_built_tree_gives_the_same_frames(force_guarded):
             assert t.guarded == 1
             assert_same_frame(fb, ob.render(host, cam, threads=8), f"mixed scene {trial} on a device-built tree")
     finally:
-        os.environ.pop("RTP_BUILD", None)
+        rb.DEFAULTS.pop("tree_build", None)
 
 
 def test_guarded_walk_random_sphere_scenes(force_guarded):

@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, 'ray-tracing-practice_amd')
 import numpy as np
 import rtp_bindings as rb
+rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
 SPP = int(os.environ.get('SPP', 100)); C5SPP = int(os.environ.get('C5SPP', 16))
 for label, host, cam in (('S-rtiow 1080p', rb.HostScene.rtiow(), rb.rtiow_camera(1920, 1080, SPP, 50)),
                          ('S-100k 4K', rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=1024), rb.rtiow_camera(3840, 2160, C5SPP, 50))):

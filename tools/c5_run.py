@@ -2,6 +2,7 @@
 import os, sys, time
 _R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,os.path.join(_R,'tests')); sys.path.insert(0,os.path.join(_R,'ray-tracing-practice_amd'))
 import rtp_bindings as rb, numpy as np, oracle_bindings as ob
+rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
 import torch
 spp=int(os.environ.get('SPP',1000))
 hs=rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=2048)

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import rtp_bindings as rb
+rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
 import oracle_bindings as ob
 
 for half, (w, h, spp) in ((11, (960, 540, 32)), (158, (960, 540, 16))):

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ray-tracing-practice_amd"))
 import numpy as np
 import rtp_bindings as rb
+rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
 
 host = rb.HostScene.rtiow()
 dev = rb.DeviceScene(host, 0)

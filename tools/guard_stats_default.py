@@ -2,6 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ray-tracing-practice_amd"))
 import rtp_bindings as rb
+rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
 host = rb.HostScene.from_config(rb.host_lib().rtp_host_default_config().decode())
 cam = host.frame_camera(7)
 cam.samples_per_pixel = int(os.environ.get("SPP", "100"))

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import frame_parallel as fp
 import rtp_bindings as rb
+rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
 
 host = rb.HostScene.rtiow()
 SPP = int(os.environ.get("SPP", "500"))

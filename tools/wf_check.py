@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, 'ray-tracing-practice_amd')
 import numpy as np
 import rtp_bindings as rb
+rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
 import oracle_bindings as ob
 
 paths = int(os.environ.get('PATHS', 0)); exch = int(os.environ.get('EXCH', 0))
