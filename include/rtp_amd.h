@@ -327,7 +327,7 @@ rt_status rt_context_scene_create(rt_context *ctx, const rt_scene_desc *desc, co
  * device (hipDeviceSynchronize) before they write d_fb_sum_root, so work the caller queued on that buffer earlier, on any
  * stream, is complete by then; they return after their own writes are complete.  The caller must not use the buffer from
  * another thread during the call.  With more than one device the RCCL transport has run on real hardware only as a
- * one-device self-gather so far (DESIGN.md §7). */
+ * one-device self-gather so far (DESIGN.md §6). */
 rt_status rt_render_sharded(rt_context *ctx, const rt_camera_data *cam, int32_t band_rows, float *d_fb_sum_root,
                             rt_timing *timings);
 /* The collective alone: assembles the rows the devices hold from the last rt_render_sharded of this geometry. */

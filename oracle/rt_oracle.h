@@ -5,7 +5,7 @@
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under
  * ray-tracing-practice_amd/ may include, link or call it.
  *
- * Pinning (see DESIGN.md "Oracle"): the reference itself cannot be built in this image without
+ * Pinning: the reference itself cannot be built in this image without
  * writing stand-ins for cuda_runtime.h / curand_kernel.h, which is not allowed, so this oracle is
  * pinned by the known answers SURVEY.md §4 recorded from the reference's own CPU path
  * (wang_hash / random_float vectors, the CameraData of the create_test_config.py scene, and the

@@ -706,7 +706,7 @@ void Packer::pair_tables() {
     // ---- 4-wide nodes (Guarded, host-built tree): the binary tree collapsed — an inner child is replaced by its own
     // two children, largest box first, until the node has four children or only leaves.  Half the steps per ray for
     // slightly FEWER box tests (tools/nearfirst_study.c WIDE=1: S-rtiow 5.4 steps / 20.1 box tests per ray instead of
-    // 10.8 / 22.6; S-100k 10.1 / 39.5 instead of 20.0 / 41.1).  Same boxes, same leaves: everything DESIGN.md §3b says
+    // 10.8 / 22.6; S-100k 10.1 / 39.5 instead of 20.0 / 41.1).  Same boxes, same leaves: everything docs/LOG.md §3b says
     // about the guarded walk holds unchanged.  Nodes are numbered breadth-first (top of the tree first, for the LDS
     // treelet of big scenes).
     //   wnodes  (fp32, 7 x float4): lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] code[4]

@@ -53,7 +53,7 @@ struct Packed {
     std::vector<float> wnodes;     // 28 floats per wide node (fp32 boxes)
     std::vector<float> whnodes;    // 16 floats per wide node (binary16 boxes rounded outward)
     int32_t num_wide = 0, num_top_wide = 0, wroot = kTraversalDone, wide_depth = 0;
-    // Guarded near-first walk (TreeMode::Guarded): `nodes` then is an SAH tree over
+    // Guarded near-first walk (TreeMode::Guarded, docs/LOG.md §3b): `nodes` then is an SAH tree over
     // leaf boxes INFLATED by a per-sphere margin, and the kernel sends every sample whose result
     // could depend on the visit order to the exact reference-order walk.  guard.ok == false (with
     // a reason) → the scene is not eligible and only the reference-order walk may be used.
@@ -86,7 +86,7 @@ struct Packed {
 // guard_leaf_boxes / guard_leaf_codes for a device-side builder (rt_build.h).
 enum class TreeMode { Reference, Sah, Guarded, GuardedLeaves };
 
-// Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2.
+// Rounding-error budget of hit_sphere's discriminant in units of |oc|^2 |d|^2 (see docs/LOG.md §3b).
 // kGuardGammaBound: the sum of every rounding's worst case is ~21 x 2^-24; 24 is what every scene gets by default.
 // kGuardGammaObserved: 16x the largest error observed in ~10^8 sphere tests — NOT a bound; only used when the caller
 // opts in through rt_config.guard_gamma_ulps (reported as rt_timing.guard_unproven).

@@ -10,7 +10,7 @@
 // AXIS RAY meets B grown by rho = D k on every side.  beam_hits_box() tests exactly that (slab test in double, rho rounded up
 // by a relative 1e-6 and an absolute term of a few hundred float ulps of the coordinates involved).
 //
-// What it is for (rt_primary.hip.inc): the guarded near-first walk rests on ONE geometric fact — a primitive
+// What it is for (rt_primary.hip.inc): the guarded near-first walk (docs/LOG.md §3b) rests on ONE geometric fact — a primitive
 // for which hit_sphere / hit_plane can return a hit for a ray has its computed hit point inside the primitive's INFLATED leaf
 // box (the box the walk's tree is built from).  A primitive whose inflated leaf box no ray of the pixel can meet can therefore
 // not be hit by any sample of the pixel; the others are the pixel's candidates, and testing all of them gives the closest

@@ -1,6 +1,6 @@
 // rt_build.h — device-side builder of the guarded walk's traversal tree.
 //
-// The guarded walk re-walks every order-sensitive sample on the CALLER's tree, so
+// The guarded walk (docs/LOG.md §3b) re-walks every order-sensitive sample on the CALLER's tree, so
 // the tree it walks first may be ANY tree whose boxes contain the inflated leaf boxes: the image is
 // the same bits.  That frees the choice of builder: this one is an LBVH (63-bit Morton codes of the
 // box centres, device radix sort, Karras' parallel hierarchy, bottom-up refit), with the few

@@ -71,7 +71,7 @@ constexpr int kQueueWords = 4 * kMaxPasses + 16;
 // Traversal (rt_config.traversal).  EXACT ("threaded"): the caller's tree in the reference's own visit order — the
 // result is the reference's by construction.  GUARDED (AUTO's choice where the scene is eligible): near-first walk
 // of an SAH tree over inflated leaf boxes; every sample whose result could depend on the visit order
-// is flagged and re-walked in threaded mode, so the frame is the same.
+// is flagged and re-walked in threaded mode, so the frame is the same (docs/LOG.md §3b).
 // Trees of a handful of primitives have nothing to gain from a second walk; everything else eligible gets the
 // guarded one (the reference's default scene, ~200 primitives: 12.4 vs 9.0 Gsamples/s).
 bool guarded_wanted(const rt_config &cfg, int64_t primitives) {
@@ -425,7 +425,7 @@ rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cf
     rtaccel::Packed pk;
     const rtaccel::PackOptions popt = pack_options(cfg);
     // RT_BUILD_DEVICE_LBVH: the guarded walk's tree is built on the GPU (LBVH, rt_build.hip) instead of the host's SAH
-    // builder — any tree over the inflated leaves gives the same image
+    // builder — any tree over the inflated leaves gives the same image (docs/LOG.md §3b)
     const bool device_build = cfg.tree_build == RT_BUILD_DEVICE_LBVH;
     std::string err = rtaccel::pack_scene(*desc, device_build ? rtaccel::TreeMode::GuardedLeaves : rtaccel::TreeMode::Guarded, pk, popt);
     if (!err.empty()) return fail(RT_ERR_INVALID_ARG, err);

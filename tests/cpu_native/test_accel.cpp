@@ -146,7 +146,7 @@ int main() {
         CHECK(rtaccel::pack_scene(empty.desc(), rtaccel::TreeMode::Sah, pk).empty());
         CHECK(pk.num_tnodes == 0 && pk.root == rtaccel::kTraversalDone);
     }
-    {   // guarded-walk parameters
+    {   // guarded-walk parameters (docs/LOG.md §3b)
         rtp::RtiowOptions o;
         o.half_extent = 11;
         rtp::HostScene hs;

@@ -1,4 +1,4 @@
-/* CPU check of the error budget behind the guarded walk's margins (rt_accel.h kGuardGammaBound):
+/* CPU check of the error budget behind the guarded walk's margins (docs/LOG.md §3b item 3, rt_accel.h kGuardGammaBound):
  * every hit the reference's hit_sphere COMPUTES — a true hit with a rounded root, or a phantom hit of a ray that
  * misses — lies within  gamma |o - c|^2 / (2 r)  of the sphere's surface, gamma = 24 * 2^-24.
  * Adversarial rays: far origins (up to 2000 units), tiny radii (down to 0.01), directions aimed AT the silhouette and a

@@ -23,7 +23,7 @@ def test_accel_tables_under_sanitizers(tmp_path):
 
 def test_margin_budget_against_adversarial_rays(tmp_path):
     """The error budget behind the guarded walk's margins (gamma = 24 ulp of |oc|^2 |d|^2 in hit_sphere's discriminant,
-    DESIGN.md §3b): 400 k rays aimed at and around the silhouettes of tiny spheres from up to 2 000 units away — where
+    docs/LOG.md §3b): 400 k rays aimed at and around the silhouettes of tiny spheres from up to 2 000 units away — where
     hb^2 - a*c cancels — through the oracle's hit_sphere; every computed hit, true or phantom (a quarter of them are
     phantom hits of rays that miss), must lie within gamma |oc|^2 / (2 r) of the surface.  The largest budget these rays
     actually use is just under 8 ulp — which is why 8 (round 1's margin for big scenes) is not a bound and 24 is."""

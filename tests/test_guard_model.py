@@ -1,4 +1,4 @@
-"""CPU model of the guarded near-first walk against the oracle's hit_bvh.
+"""CPU model of the guarded near-first walk (docs/LOG.md §3b) against the oracle's hit_bvh.
 
 tools/nearfirst_study.c restates the scheme in plain C on top of the oracle's own primitive tests:
 SAH tree over leaf boxes inflated by the per-sphere margin, near-first walk with the fused box

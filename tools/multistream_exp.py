@@ -1,5 +1,5 @@
 """Experiment (GPU): one frame rendered as K row shards on K streams / K scene handles concurrently — the experiment
-that exposed the contended work counter.  One script for the three sweeps that used to be separate files:
+that exposed the contended work counter (docs/LOG.md §6).  One script for the three sweeps that used to be separate files:
 
   KS=1,2,4 python tools/multistream_exp.py                 K concurrent shard launches, frames checked against K=1
   PRIOS=1 python tools/multistream_exp.py                  K=2 with equal / different stream priorities

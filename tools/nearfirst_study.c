@@ -164,7 +164,7 @@ static unsigned long long n_far, n_far_flag;
 static float g_bs[6], g_rs, g_fark;
 static int g_levels = 64;
 static float *g_rmax;            /* per SAH node: largest radius below */
-/* DYN=1: distance-aware margins (DESIGN.md §3b "dynamic margins"): the small spheres' leaf boxes carry only the
+/* DYN=1: distance-aware margins (docs/LOG.md §3b "dynamic margins"): the small spheres' leaf boxes carry only the
  * rounding floor, and every box test of the walk grows the box by g_dynk * (distance from the ray origin to the
  * box's farthest corner)^2 — an upper bound of gamma |o - c_q|^2 / (2 r_q) for every small sphere q below. */
 static int g_dyn = 0;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiles of the default bench.py run, as DESIGN.md §6 / profiles/rNN cite them.  Run on the GPU box:
+# Profiles of the default bench.py run, as docs/LOG.md §6 / profiles/rNN cite them.  Run on the GPU box:
 #   gpurun --timeout 900 -- 'bash tools/profile_bench.sh r01'
 # Kernel trace and each PMC group are separate rocprofv3 runs (never --pmc together with tracing).
 set -eo pipefail
