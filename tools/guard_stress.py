@@ -51,6 +51,6 @@ for trial in range(N):
     bad = int((g.view(np.uint32) != e.view(np.uint32)).any(axis=-1).sum())
     total_bad += bad
     total_samples += W * H * SPP
-    print(f"scene {trial:2d}: {n:5d} spheres {n_pl:2d} planes spread {spread:5.1f} | guarded {tg.guarded} ({dev.guard_reason() or 'eligible'}) "
+    print(f"scene {trial:2d}: {n:5d} spheres {n_pl:2d} planes spread {spread:5.1f} | guarded {tg.guarded} primary pass {tg.primary_visibility} ({dev.guard_reason() or 'eligible'}) "
           f"flagged {100.0 * tg.flagged_samples / (W * H * SPP):7.4f} % | {tg.kernel_ms:7.2f} ms vs exact {te.kernel_ms:7.2f} ms | differing pixels {bad}", flush=True)
 print(f"TOTAL: {N} scenes, {total_samples / 1e9:.2f} G samples, differing pixels {total_bad}")
