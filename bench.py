@@ -492,7 +492,8 @@ def worker(args):
             "kernel_resources": ({"vgprs_per_lane": int(last_t[0].trace_vgprs), "scratch_bytes_per_lane": int(last_t[0].trace_scratch_bytes),
                                   "workgroup_size": int(last_t[0].workgroup_size), "workgroups": int(last_t[0].num_workgroups),
                                   "lds_bytes_per_workgroup": int(last_t[0].lds_bytes),
-                                  "waves_per_simd": int(last_t[0].workgroup_size) // 64 * (int(last_t[0].num_workgroups) // 256) // 4,
+                                  "waves_per_simd": int(last_t[0].workgroup_size) // 64 * int(last_t[0].num_workgroups)
+                                                    // max(torch.cuda.get_device_properties(local_rank).multi_processor_count, 1) // 4,
                                   "source": "hipFuncGetAttributes of the loaded code object + the launch shape of this run"}
                                  if last_t[0] is not None else None),
             "primary_visibility_pass_ms": round(float(np.mean(primary_ms)), 3) if primary_ms else None,
