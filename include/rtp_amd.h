@@ -191,7 +191,7 @@ typedef struct rt_config {
     int32_t  scene_in_lds;        /* 1 (default): stage tables in LDS when they fit; 0: read them through L1/L2 */
     int32_t  lds_treelet;         /* 1 (default): scenes too big for LDS keep the top of their tree there */
     int32_t  workgroups_per_cu;   /* 0 = auto */
-    int32_t  k_inner, k_shade;    /* wave scheduling thresholds in lanes (0 = defaults: 24 / 48, 32 / 52 for the LDS-resident guarded walk) */
+    int32_t  k_inner, k_shade;    /* wave scheduling thresholds in lanes (0 = defaults: 24 / 48; 32 / 52 for the LDS-resident guarded walk, 48 / 52 for big scenes with distance-aware margins) */
     int32_t  reserve_chunk;       /* work indices per queue reservation in units of 64 (0 = auto) */
     int32_t  reserve_taper;       /* 1 (default): reservations shrink towards the end of a pass */
     int32_t  wavefront_paths;     /* RT_KERNEL_WAVEFRONT: paths in flight per wave, >= 128 (0 = auto) */

@@ -964,6 +964,11 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             const bool octant_launch = (RTP_OCTANT != 0) && fast.in_lds && !wide && !wavefront && !dyn;
             if (octant_launch && sc->cfg.k_inner <= 0) P.k_inner = 32;
             if (octant_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
+            // big scene with distance-aware margins (tables through L1/L2, step_pair_dyn): a block of pair steps costs memory round
+            // trips on top of its instructions — worth starting only for a nearly full wave (S-100k, swept 16-52 x 44-56: +4 %)
+            const bool big_dyn_launch = dyn && !fast.in_lds && !wide && !wavefront;
+            if (big_dyn_launch && sc->cfg.k_inner <= 0) P.k_inner = 48;
+            if (big_dyn_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
             P.flag_list = sc->flag_list;
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.dirty = overlap ? sc->dirty : nullptr;
