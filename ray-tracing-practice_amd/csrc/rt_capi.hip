@@ -822,8 +822,14 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         (void)hipFree(sc->cand);
         sc->cand = nullptr;
         sc->cand_pixels = 0;
-        HIP_TRY(hipMalloc((void **)&sc->cand, (size_t)num_pixels * rtk::kCandWords * sizeof(uint32_t)));
-        sc->cand_pixels = (size_t)num_pixels;
+        // (64 bytes per pixel; a device short of memory renders without the pass rather than not at all)
+        if (hipMalloc((void **)&sc->cand, (size_t)num_pixels * rtk::kCandWords * sizeof(uint32_t)) == hipSuccess) {
+            sc->cand_pixels = (size_t)num_pixels;
+        } else {
+            (void)hipGetLastError();
+            sc->cand = nullptr;
+            prim = false;
+        }
     }
     P.cand = prim ? sc->cand : nullptr;
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
