@@ -823,7 +823,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         sc->cand = nullptr;
         sc->cand_pixels = 0;
         // (64 bytes per pixel; a device short of memory renders without the pass rather than not at all)
-        if (hipMalloc((void **)&sc->cand, (size_t)num_pixels * rtk::kCandWords * sizeof(uint32_t)) == hipSuccess) {
+        // + 4 bytes per pixel for the fetch order and 12 per 256 pixels for its counting sort (order_* kernels)
+        const size_t cand_words = (size_t)num_pixels * (rtk::kCandWords + 1) + 3 * (((size_t)num_pixels + rtk::kOrderBlock - 1) / rtk::kOrderBlock);
+        if (hipMalloc((void **)&sc->cand, cand_words * sizeof(uint32_t)) == hipSuccess) {
             sc->cand_pixels = (size_t)num_pixels;
         } else {
             (void)hipGetLastError();
@@ -832,10 +834,20 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         }
     }
     P.cand = prim ? sc->cand : nullptr;
+    P.order = prim ? sc->cand + sc->cand_pixels * rtk::kCandWords : nullptr;
+    P.traced_pixels = prim ? P.order + sc->cand_pixels + 2 * (((size_t)num_pixels + rtk::kOrderBlock - 1) / rtk::kOrderBlock) : nullptr;      // counts[2 * blocks] after the scan
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
     if (prim) {
         const double coord_max = rtbeam::coord_bound(cam->origin.e, cam->pixel00_loc.e, cam->pixel_delta_u.e, cam->pixel_delta_v.e, cam->image_width, cam->image_height);
         hipLaunchKernelGGL(rtk::cand_kernel, dim3((num_pixels + 255u) / 256u), dim3(256), 0, stream, P, sc->cand, coord_max);
+        HIP_TRY(hipGetLastError());
+        // the order the trace kernel fetches the pixels in: expensive ones first (rt_primary.hip.inc)
+        uint32_t *order = sc->cand + sc->cand_pixels * rtk::kCandWords, *counts = order + sc->cand_pixels;
+        const uint32_t order_blocks = (num_pixels + (uint32_t)rtk::kOrderBlock - 1u) / (uint32_t)rtk::kOrderBlock;
+        hipLaunchKernelGGL(rtk::order_count_kernel, dim3(order_blocks), dim3(rtk::kOrderBlock), 0, stream, (const uint32_t *)sc->cand, num_pixels, order_blocks, counts);
+        hipLaunchKernelGGL(rtk::order_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, 3u * order_blocks);
+        hipLaunchKernelGGL(rtk::order_scatter_kernel, dim3(order_blocks), dim3(rtk::kOrderBlock), 0, stream, (const uint32_t *)sc->cand, num_pixels, order_blocks,
+                           (const uint32_t *)counts, order);
         HIP_TRY(hipGetLastError());
     }
     hipStream_t launch_stream = stream;       // the exact re-walk may go to the handle's second stream (overlap_rework)
