@@ -64,6 +64,9 @@ constexpr int kTimedPasses = 64;        // trace launches individually timed per
 
 // Counter block of a scene handle (uint32 words): work counters of the trace launches, of the exact
 // re-walk launches, the flagged-sample counts (one each per pass), then 16 developer words.
+#ifndef RTP_TAPER_FACTOR
+#define RTP_TAPER_FACTOR 2          /* reservations shrink to remaining / (this x waves) */
+#endif
 constexpr int kQueueWork = 0, kQueueRework = kMaxPasses, kQueueFlag = 2 * kMaxPasses, kQueueStats = 3 * kMaxPasses;
 constexpr int kQueueDirty = 3 * kMaxPasses + 16;      // per pass: pixels with a flagged sample (overlapped re-walk)
 constexpr int kQueueWords = 4 * kMaxPasses + 16;
@@ -934,7 +937,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         P.pass_count = P.spp - P.pass_first < pass_size ? P.spp - P.pass_first : pass_size;
         P.total_work = num_pixels * (uint32_t)P.pass_count;      // work index = pixel * pass_count + slot
         P.slab_pitch = pitch_of(pass_size);
-        if (!make_magic((uint32_t)P.pass_count, (uint64_t)P.total_work + 64, P.magic_count))
+        if ((uint64_t)num_pixels * (uint64_t)P.pass_count >= (1ull << 31) - 4096 || !make_magic((uint32_t)P.pass_count, (uint64_t)P.total_work + 64, P.magic_count))
             return fail(RT_ERR_UNSUPPORTED, "image too large for the work index arithmetic");
         P.queue = sc->queue + kQueueWork + pass;
         P.work_list = nullptr;
@@ -948,7 +951,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             if (const int forced = cfg.reserve_chunk) per = (uint64_t)(forced > 0 ? forced : 1);
             P.chunk = (uint32_t)(64u * per);
             P.taper_shift = 1;                      // remaining / (2 x waves), rounded to a power of two
-            while (((uint64_t)1 << P.taper_shift) < 2 * waves_total) ++P.taper_shift;
+            while (((uint64_t)1 << P.taper_shift) < RTP_TAPER_FACTOR * waves_total) ++P.taper_shift;
             if (!cfg.reserve_taper) P.taper_shift = 0;
         }
         if (prim) {
