@@ -178,6 +178,53 @@ def test_primary_visibility_pass_changes_nothing_but_the_time(config_scene):
             assert_same_frame(a, ob.render(hostc, cam, threads=8), "config scene against the oracle")
 
 
+def test_sky_pixels_and_the_fetch_order(config_scene):
+    """The primary pass finishes sky pixels itself and the trace kernel takes the other pixels through a table, expensive ones
+    first (rt_primary.hip.inc, order_* kernels); at the end of a pass the waves of a workgroup take what the others still
+    hold.  Frames against the oracle where those paths have their corners: nothing but sky (no pixel for the trace kernel),
+    no sky at all, sky with a background of negative zeros (0 + 1 * -0 is +0), fewer pixels than one block of the sort, more
+    samples than pixels, both primary kernels (passes under and over 128 samples), several passes, a row shard, a tile."""
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    sky = (0.7, 0.8, 1.0)
+    cases = [("all sky", rb.make_camera(64, 36, 20.0, (13, 3, 2), (26, 6, 40), sky, 9, 50), None),
+             ("all sky, pixel pass", rb.make_camera(8, 8, 20.0, (13, 3, 2), (26, 6, 40), sky, 130, 50), None),
+             ("no sky", rb.make_camera(96, 54, 30.0, (13, 3, 6), (0, 0, -2), sky, 12, 50), None),
+             ("negative zero background", rb.make_camera(48, 27, 40.0, (13, 3, 2), (0, 0, 3), (-0.0, 0.25, -0.0), 140, 50), None),
+             ("three pixels", rb.rtiow_camera(3, 1, 700, 50), None),
+             ("one pixel of sky", rb.make_camera(1, 1, 1.0, (13, 3, 2), (26, 6, 40), sky, 5, 50), None),
+             ("shard", rb.rtiow_camera(160, 90, 24, 50), rb.Shard(8, 3, 2)),
+             ("horizon", rb.make_camera(320, 20, 20.0, (13, 3, 0.5), (0, 0, 0.5), sky, 200, 50), None)]
+    for what, cam, shard in cases:
+        fb, t = dev.render_to_host(cam, shard)
+        assert t.primary_visibility == 1 and t.guarded == 1, what
+        rows = None if shard is None else [r for r in range(cam.image_height) if (r // shard.band_rows) % shard.num_parts == shard.part]
+        want = ob.render(host, cam, threads=8)
+        assert_same_frame(fb, want if rows is None else want[rows], what)
+        if what.startswith("all sky"):
+            assert t.flagged_samples == 0 and np.unique(bits(fb).reshape(-1, 3), axis=0).shape[0] == 1
+    # several passes, and a tile cut out of the frame
+    cam = rb.rtiow_camera(96, 54, 300, 50)
+    dev.configure(pass_spp=70)
+    fb, t = dev.render_to_host(cam)
+    dev.configure(pass_spp=0)
+    assert t.trace_launches == 5
+    want = ob.render(host, cam, threads=8)
+    assert_same_frame(fb, want, "five passes")
+    tile, _ = dev.render_tile_to_host(cam, 17, 0, 40, 23)
+    assert_same_frame(tile, want[0:23, 17:57], "tile over sky and ground")
+    dev.close()
+    # the general kernel (planes, emitters) over a frame that is mostly background
+    hostc, devc = config_scene
+    eye = list(hostc.frame_camera(0).origin.e)
+    cam = rb.make_camera(120, 68, 100.0, eye, (0.0, 0.0, 4.5), (0.1, 0.2, 0.3), 130, 10)
+    devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_GUARDED)
+    fb, t = devc.render_to_host(cam)
+    devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_AUTO)
+    assert t.primary_visibility == 1 and t.sphere_only == 0
+    assert_same_frame(fb, ob.render(hostc, cam, threads=8), "config scene, wide view")
+
+
 def test_samples_accumulate_in_order(rtiow):
     """Linearity-style property usable at any size: the 64-spp pixel sum is the in-order float sum
     of the 64 per-sample radiances (src/camera.cu:27-31)."""
