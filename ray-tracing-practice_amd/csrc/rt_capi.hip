@@ -1064,12 +1064,12 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             HIP_TRY(hipEventRecord(sc->ev_join, sc->aux_stream));
             // … while every other pixel is accumulated here
             hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
-                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)nullptr, (const uint32_t *)nullptr, P.cand, (uint32_t)rtk::kCandWords, P.bg[0], P.bg[1], P.bg[2]);
             HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join, 0));
             join_guard.forked = false;
         } else {
             hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
-                               P.pass_count, pass == 0 ? 1 : 0, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                               P.pass_count, pass == 0 ? 1 : 0, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, P.cand, (uint32_t)rtk::kCandWords, P.bg[0], P.bg[1], P.bg[2]);
         }
     }
     HIP_TRY(hipGetLastError());
