@@ -77,8 +77,11 @@ traffic = {
 }
 rows_bytes = bench["roofline"]["samples_per_launch"] * 12
 traffic["slab_rows_bytes_per_launch"] = rows_bytes
-traffic["trace_write_amplification"] = round(w[("trace", "WRITE_SIZE")] * 1024 / rows_bytes, 3)
-traffic["primary_write_amplification"] = round(w.get(("primary", "WRITE_SIZE"), 0.0) * 1024 / rows_bytes, 3)
+# Sky pixels have no rows any more (nobody writes or reads them); the primary pass writes every OTHER row exactly once, in whole
+# lines (1.003 x when it still wrote all rows) — its write bytes are the size of the rows the trace kernel then overwrites
+traced_rows = w.get(("primary", "WRITE_SIZE"), 0.0) * 1024 or rows_bytes
+traffic["traced_rows_bytes_per_launch"] = int(traced_rows)
+traffic["trace_write_amplification"] = round(w[("trace", "WRITE_SIZE")] * 1024 / traced_rows, 3)
 traffic["frame_total_bytes"] = sum(traffic[k] for k in ("bytes_per_trace_launch", "bytes_per_rework_launch", "bytes_per_accumulate_launch",
                                                          "bytes_per_accumulate_list_launch", "bytes_per_primary_launch", "bytes_per_candidates_launch")) * int(launches and 1)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
