@@ -102,6 +102,37 @@ RT_BEAM_HD bool beam_hits_box(const Beam &b, const float lo[3], const float hi[3
     return !(tmax < tmin);
 }
 
+// The same question for a SPHERE leaf, asked of the sphere instead of its box.  hit_sphere reports a hit only if its float
+// discriminant is >= 0, and then the true distance from the centre to the ray's LINE is at most r + e, e the leaf's margin
+// (docs/LOG.md §3b: disc >= -gamma |oc|^2 |d|^2 gives dist^2 <= r^2 + gamma |oc|^2) — the inflated leaf box [c -/+ (r + e)]
+// is that ball's bounding cube, so the ball is (centre, half-width) of the box.  Let p be the point of such a ray's line
+// nearest to c: |p - c| <= r + e and |p - O| <= |c - O| + r + e =: L; p is at most L sin(phi) <= L k away from the AXIS line.
+// Hence: a sphere whose test can report a hit for any ray of the pixel has its centre within (r + e) + L k of the axis line.
+// (A cube's corners stick out of its ball by a factor sqrt 3: the strip of pixels between the horizon and the silhouette of a
+// huge ground sphere passes the box test and fails this one.)  false only if certainly not.
+RT_BEAM_HD bool beam_hits_ball(const Beam &b, const float lo[3], const float hi[3], double grow_k) {
+    if (!(b.k >= 0.0)) return true;
+    double w[3], r0 = 0.0, w2 = 0.0, a2 = 0.0, wa = 0.0, cm = b.o_max;
+    for (int c = 0; c < 3; ++c) {
+        const double m = 0.5 * ((double)lo[c] + (double)hi[c]), h = 0.5 * ((double)hi[c] - (double)lo[c]);
+        r0 = h > r0 ? h : r0;
+        w[c] = m - b.o[c];
+        w2 += w[c] * w[c];
+        a2 += b.a[c] * b.a[c];
+        wa += w[c] * b.a[c];
+        const double m0 = fabs((double)lo[c]), m1 = fabs((double)hi[c]);
+        cm = m0 > cm ? m0 : cm;
+        cm = m1 > cm ? m1 : cm;
+    }
+    if (!(w2 < 1e300) || !(a2 > 0.0) || !(a2 < 1e300)) return true;
+    const double far = sqrt(w2) + 1.7320508075688772 * r0;           // the farthest corner of the cube, as beam_hits_box measures D
+    const double ball = r0 + grow_k * far * far;
+    const double rho = (ball + (sqrt(w2) + ball) * b.k) * (1.0 + 1e-6) + 256.0 * 5.9604644775390625e-8 * cm;
+    // squared distance from the centre to the axis line: |w|^2 - (w . a)^2 / |a|^2, compared without the division
+    const double lhs = (w2 * a2 - wa * wa) * (1.0 - 1e-9);           // (cancellation: the subtraction loses relative 1e-16 of w2 a2)
+    return !(lhs > rho * rho * a2 + 1e-12 * w2 * a2);
+}
+
 // Descent of the guarded walk's child-pair table (rt_accel.h: 16 floats per inner node — lo0.xyz hi0.xyz lo1.xyz hi1.xyz,
 // code0, code1; code >= 0 inner node, < 0 leaf = -(2 index + type) - 1) with the pixel's cone: writes the leaf codes of the
 // candidates (as 2 index + type) to out[0 .. max_out) and returns their number, or -1 when there are more than max_out or
@@ -128,8 +159,10 @@ RT_BEAM_HD int beam_candidates(const Beam &b, NodeTab nodes, int32_t root, doubl
             const float lo[3] = {r[6 * c + 0], r[6 * c + 1], r[6 * c + 2]}, hi[3] = {r[6 * c + 3], r[6 * c + 4], r[6 * c + 5]};
             if (!beam_hits_box(b, lo, hi, grow_k)) continue;
             if (code.i < 0) {
+                const uint32_t leaf = (uint32_t)(-(code.i + 1));
+                if (!(leaf & 1u) && !beam_hits_ball(b, lo, hi, grow_k)) continue;      // a sphere the cone passes by
                 if (n >= max_out) return -1;
-                out[n++] = (uint32_t)(-(code.i + 1));
+                out[n++] = leaf;
             } else if (next == kDoneCode) {
                 next = code.i;
             } else {
