@@ -208,7 +208,10 @@ typedef struct rt_config {
                                      second stream of the handle beside the accumulation of all other pixels; -1: one after the other */
     int32_t  primary_visibility;  /* 0 (default): where the guarded walk's tables are LDS-resident, the first hit of every camera ray
                                      comes from a per-pixel candidate list (the leaves the pixel's cone of rays can reach, made once per
-                                     frame) instead of a walk per sample — the same frame bit for bit; -1: camera rays walk the tree */
+                                     frame; 68 bytes per pixel of device memory, taken on demand — without it the frame is rendered the
+                                     other way) instead of a walk per sample; pixels no leaf can be hit through get the background
+                                     without any per-sample work, the others are traced expensive ones first — the same frame bit for
+                                     bit; -1: camera rays walk the tree */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */
