@@ -133,7 +133,11 @@ typedef struct rt_shard {
     int32_t part;
 } rt_shard;
 
+/* What a render call did and what it cost.  An OUT structure that grows with the library: the caller sets struct_bytes to the
+ * sizeof(rt_timing) it was compiled with (rt_timing_init does) and the library writes at most that many bytes — a caller built
+ * against an older, shorter header keeps working.  struct_bytes smaller than the first two fields is RT_ERR_INVALID_ARG. */
 typedef struct rt_timing {
+    uint32_t struct_bytes;    /* in: sizeof(rt_timing) as the caller compiled it */
     float    kernel_ms;       /* hipEvent time from the first to after the last kernel of the call, on the given stream */
     uint32_t num_workgroups;
     uint32_t workgroup_size;
@@ -153,7 +157,13 @@ typedef struct rt_timing {
     float    primary_ms;      /* … its launches' hipEvent durations (candidate lists + one pass per trace launch) */
     uint32_t trace_vgprs;     /* vector registers per lane of the trace kernel that ran, as the loaded code object reports them */
     uint32_t trace_scratch_bytes; /* … and its scratch (spill) bytes per lane */
+    uint32_t abandoned_passes; /* guarded passes that gave up part-way because too many of their samples were being flagged
+                                  (rt_config.guard_bail_share): the exact walk rendered those passes whole */
+    uint32_t guard_paused;    /* 1: this handle has stepped aside to the exact walk for its next frames (a frame abandoned a pass or
+                                  flagged more than the bail share of its samples; rt_config.guard_keep = 1 prevents it) */
 } rt_timing;
+/* *t = zeros with struct_bytes = sizeof(rt_timing). */
+void rt_timing_init(rt_timing *t);
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident repacked scene */
 
@@ -175,9 +185,13 @@ typedef struct rt_config {
     int32_t  guard_exact_leaf_table; /* 1: always upload the exact leaf boxes as a table (developer) */
     /* --- may be changed between frames with rt_scene_set_config ----------------------------------- */
     int32_t  traversal;           /* RT_TRAVERSAL_*: AUTO = guarded near-first walk where the scene is eligible and
-                                     has at least guard_min_primitives primitives, else the reference-order walk */
-    int32_t  guard_min_primitives;/* default 16 */
-    int32_t  guard_keep;          /* 1: keep the guarded walk even after a frame that flagged > 2 % of its samples */
+                                     has at least guard_min_primitives primitives, else the reference-order walk.  AUTO also
+                                     MEASURES: a guarded frame that flagged more than 0.4 % of its samples is followed by one
+                                     frame on the exact walk, and the handle keeps whichever cost less per sample (same bits
+                                     either way).  GUARDED / EXACT: that walk, no measuring */
+    int32_t  guard_min_primitives;/* default 64: below that the exact walk's tree is a few levels deep and the second launch the
+                                     guarded walk needs costs more than it saves (random scenes of 20-60 spheres: 1.3-1.4 x slower) */
+    int32_t  guard_keep;          /* 1: keep the guarded walk even after a frame that flagged more than the bail share of its samples */
     int32_t  guard_repack;        /* 1 (default): re-pack the guarded tree for a camera outside the reach it was sized for */
     int32_t  kernel;              /* RT_KERNEL_*: AUTO picks per scene */
     uint64_t workspace_bytes;     /* budget of the per-pass sample workspace the scene handle owns (12 bytes per sample of a
@@ -212,6 +226,12 @@ typedef struct rt_config {
                                      other way) instead of a walk per sample; pixels no leaf can be hit through get the background
                                      without any per-sample work, the others are traced expensive ones first — the same frame bit for
                                      bit; -1: camera rays walk the tree */
+    int32_t  guard_bail_share;    /* what the guarded walk may cost before it steps aside, as the share of flagged samples in 1/256ths
+                                     (0 = default: 24, i.e. 9.4 %; -1: never).  Inside a pass: once the flagged share of the samples
+                                     handed out so far exceeds it, the waves stop fetching and the exact walk renders the WHOLE pass
+                                     (bounded loss: what the guarded launch had done).  Between frames: a frame that abandoned a pass,
+                                     or flagged more than this share overall, makes the handle use the exact walk from then on — found
+                                     at the next render call from counts the previous one left in host memory, no rt_last_timing needed */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */
@@ -325,7 +345,7 @@ const char *rt_context_transport(const rt_context *ctx);
 /* rt_scene_create_ex on every device of the context (replaces the context's previous scene). */
 rt_status rt_context_scene_create(rt_context *ctx, const rt_scene_desc *desc, const rt_config *cfg);
 /* Camera::render for the whole node: d_fb_sum_root is image_height*image_width*3 floats on the ROOT device; returns
- * when the assembled frame is there.  band_rows <= 0: 8.  timings: NULL or num_devices entries (per-device rt_timing).
+ * when the assembled frame is there.  band_rows <= 0: 8.  timings: NULL or num_devices entries (per-device rt_timing; every entry initialised with rt_timing_init — the first entry's struct_bytes is the array stride).
  * Stream contract: the context works on non-blocking streams of its own.  rt_render_sharded and rt_gather drain the root
  * device (hipDeviceSynchronize) before they write d_fb_sum_root, so work the caller queued on that buffer earlier, on any
  * stream, is complete by then; they return after their own writes are complete.  The caller must not use the buffer from

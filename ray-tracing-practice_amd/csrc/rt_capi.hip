@@ -69,13 +69,21 @@ constexpr int kTimedPasses = 64;        // trace launches individually timed per
 #endif
 constexpr int kQueueWork = 0, kQueueRework = kMaxPasses, kQueueFlag = 2 * kMaxPasses, kQueueStats = 3 * kMaxPasses;
 constexpr int kQueueDirty = 3 * kMaxPasses + 16;      // per pass: pixels with a flagged sample (overlapped re-walk)
-constexpr int kQueueWords = 4 * kMaxPasses + 16;
+constexpr int kQueueAbandon = 4 * kMaxPasses + 16;    // per pass: the guarded launch gave up part-way (render_kernel, flag_write)
+constexpr int kQueueWords = 5 * kMaxPasses + 16;
+// What a render call leaves for the NEXT one to read (rt_scene::feedback): per pass the flagged count and the abandon word, copied
+// to pinned host memory at the end of the call, with an event — the handle's decision to step aside from the guarded walk needs no
+// rt_last_timing and no synchronisation of the caller's.
+constexpr int kFeedbackSlots = 4;
+constexpr uint32_t kDefaultBailShare = 24;            // of 256: 9.4 % (rt_config.guard_bail_share)
+constexpr uint32_t kExploreShare = 1;                 // of 256: a guarded frame that flagged more than 0.4 % is timed against an exact one
 
 // Traversal (rt_config.traversal).  EXACT ("threaded"): the caller's tree in the reference's own visit order — the
 // result is the reference's by construction.  GUARDED (AUTO's choice where the scene is eligible): near-first walk
 // of an SAH tree over inflated leaf boxes; every sample whose result could depend on the visit order
 // is flagged and re-walked in threaded mode, so the frame is the same (docs/LOG.md §3b).
-// Trees of a handful of primitives have nothing to gain from a second walk; everything else eligible gets the
+// Trees of a few dozen primitives have nothing to gain from a second walk (random scenes of 20-60 spheres: the guarded frame
+// 1.3-1.4 x the exact one — its re-walk launch is a fixed half millisecond); everything else eligible gets the
 // guarded one (the reference's default scene, ~200 primitives: 12.4 vs 9.0 Gsamples/s).
 bool guarded_wanted(const rt_config &cfg, int64_t primitives) {
     if (cfg.traversal == RT_TRAVERSAL_GUARDED) return true;
@@ -88,7 +96,7 @@ void config_defaults(rt_config &c) {
     c.tree_build = RT_BUILD_HOST_SAH;
     c.guard_gamma_ulps = 0.0f;
     c.traversal = RT_TRAVERSAL_AUTO;
-    c.guard_min_primitives = 16;
+    c.guard_min_primitives = 64;
     c.guard_repack = 1;
     c.kernel = RT_KERNEL_AUTO;
     c.workspace_bytes = 0;
@@ -96,6 +104,7 @@ void config_defaults(rt_config &c) {
     c.lds_treelet = 1;
     c.reserve_taper = 1;
     c.wide_nodes = 0;
+    c.guard_bail_share = 0;
 }
 
 // A caller compiled against an older, shorter rt_config: its fields, defaults for the rest.
@@ -117,6 +126,22 @@ rtaccel::PackOptions pack_options(const rt_config &cfg) {
     if (cfg.guard_gamma_ulps > 0.0f) o.gamma = (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8;
     o.leaf_table = cfg.guard_exact_leaf_table != 0;
     return o;
+}
+uint32_t bail_share_of(const rt_config &cfg) {      // in 1/256ths; 0 = never
+    if (cfg.guard_bail_share < 0) return 0u;
+    const uint32_t s = cfg.guard_bail_share == 0 ? kDefaultBailShare : (uint32_t)cfg.guard_bail_share;
+    return s > 255u ? 255u : s;
+}
+// rt_timing is an out-structure of the caller's size (include/rtp_amd.h)
+rt_status timing_check(const rt_timing *t) {
+    if (t && t->struct_bytes < 8) { g_last_error = "rt_timing.struct_bytes is not set (rt_timing_init)"; return RT_ERR_INVALID_ARG; }
+    return RT_OK;
+}
+void timing_out(const rt_timing &src, rt_timing *dst) {
+    if (!dst) return;
+    const uint32_t n = dst->struct_bytes < sizeof(rt_timing) ? dst->struct_bytes : (uint32_t)sizeof(rt_timing);
+    std::memcpy(dst, &src, n);
+    dst->struct_bytes = n;
 }
 bool gamma_unproven(const rt_config &cfg) {
     return cfg.guard_gamma_ulps > 0.0f && (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8 < (double)rtaccel::kGuardGammaBound;
@@ -147,7 +172,19 @@ struct rt_scene {
     bool device_built = false;
     int repacks = 0;
     bool repack_refused = false;    // a re-pack for a far camera was not eligible: do not try again
-    bool guard_paused = false;      // a frame flagged more than 2 % of its samples: later frames use the exact walk
+    bool guard_paused = false;      // a frame abandoned a guarded pass or flagged more than the bail share of its samples: later frames use the exact walk
+    // feedback of the last few render calls (kFeedbackSlots): [0, passes) flagged counts, [kMaxPasses, kMaxPasses + passes) abandon words
+    struct Feedback {
+        uint32_t *host = nullptr; hipEvent_t start = nullptr, done = nullptr;
+        bool pending = false, guarded = false, exploring = false;
+        int passes = 0; uint64_t samples = 0;
+    };
+    Feedback feedback[kFeedbackSlots];
+    int feedback_next = 0;
+    // RT_TRAVERSAL_AUTO's cost model is a measurement: a guarded frame that flagged more than kExploreShare of its samples makes the
+    // handle render ONE frame with the exact walk and keep whichever was faster per sample (judge_frame)
+    double guarded_ns_per_sample = 0.0, exact_ns_per_sample = 0.0;
+    bool explore_exact = false;
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
@@ -226,6 +263,8 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     std::memset(&P, 0, sizeof(P));
     if (!sc || !cam) return fail(RT_ERR_INVALID_ARG, "null scene or camera");
     if (cam->image_width <= 0 || cam->image_height <= 0) return fail(RT_ERR_INVALID_ARG, "image size must be positive");
+    // (tile offsets travel in 24 bits of the guarded kernels' constants block: fill_consts)
+    if (cam->image_width >= (1 << 24) || cam->image_height >= (1 << 24)) return fail(RT_ERR_UNSUPPORTED, "image width or height of 2^24 or more");
     if (shard && shard->num_parts > 1 && (shard->part < 0 || shard->part >= shard->num_parts || shard->band_rows <= 0))
         return fail(RT_ERR_INVALID_ARG, "bad shard");
     std::memcpy(P.origin, cam->origin.e, 12);
@@ -398,6 +437,7 @@ void rt_config_from_env(rt_config *cfg) {
     if (env_int("RTP_NO_SIMPLE", 0)) cfg->sphere_only_kernel = -1;
     if (env_int("RTP_NO_OVERLAP", 0)) cfg->overlap_rework = -1;
     if (env_int("RTP_NO_PRIMARY", 0)) cfg->primary_visibility = -1;
+    cfg->guard_bail_share = env_int("RTP_BAIL_SHARE", cfg->guard_bail_share);
 }
 
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) { return rt_scene_create_ex(desc, nullptr, out_scene); }
@@ -519,6 +559,11 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
+    for (rt_scene::Feedback &f : sc->feedback) {
+        if (f.done) { if (f.pending) (void)hipEventSynchronize(f.done); (void)hipEventDestroy(f.done); }
+        if (f.start) (void)hipEventDestroy(f.start);
+        if (f.host) (void)hipHostFree(f.host);
+    }
     delete sc;
     return RT_OK;
 }
@@ -544,6 +589,60 @@ int32_t rt_shard_rows(int32_t image_height, const rt_shard *shard) {
 }  // extern "C"
 
 namespace {
+// The handle's own judgement of its guarded walk, from what a finished render call left behind (its flagged counts, abandon words
+// and event times): a pass that gave up, or more flagged samples overall than the bail share, and the following frames go to the
+// exact walk; a frame that flagged more than kExploreShare makes the next AUTO frame an exact one, and the faster of the two per
+// sample stays (rt_config.guard_keep: the guarded walk stays whatever happens).
+rt_status judge_frame(rt_scene *sc, rt_scene::Feedback &f) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, f.start, f.done));
+    const double ns = f.samples ? (double)ms * 1e6 / (double)f.samples : 0.0;
+    const uint32_t share = bail_share_of(sc->cfg);
+    if (f.guarded) {
+        uint64_t total = 0;
+        uint32_t gave_up = 0;
+        for (int p = 0; p < f.passes; ++p) { total += f.host[p]; gave_up += f.host[kMaxPasses + p] != 0u ? 1u : 0u; }
+        if (share != 0u && (gave_up != 0u || total * 256u > (uint64_t)share * f.samples)) sc->guard_paused = true;
+        if (gave_up == 0u) sc->guarded_ns_per_sample = ns;
+        if (share != 0u && !sc->guard_paused && sc->exact_ns_per_sample == 0.0 && total * 256u > (uint64_t)kExploreShare * f.samples) sc->explore_exact = true;
+    } else if (f.exploring) {
+        sc->exact_ns_per_sample = ns;
+        sc->explore_exact = false;
+        if (sc->guarded_ns_per_sample > 0.0 && ns < 0.95 * sc->guarded_ns_per_sample) sc->guard_paused = true;
+    }
+    return RT_OK;
+}
+// feedback slots whose frames have finished are read (wait_all: every pending one is waited for)
+rt_status poll_feedback(rt_scene *sc, bool wait_all) {
+    for (int k = 0; k < kFeedbackSlots; ++k) {
+        rt_scene::Feedback &f = sc->feedback[(sc->feedback_next + k) % kFeedbackSlots];      // oldest first
+        if (!f.pending) continue;
+        if (wait_all) HIP_TRY(hipEventSynchronize(f.done));
+        const hipError_t e = hipEventQuery(f.done);
+        if (e == hipErrorNotReady) continue;
+        HIP_TRY(e);
+        f.pending = false;
+        if (const rt_status st = judge_frame(sc, f)) return st;
+    }
+    return RT_OK;
+}
+// the slot of the frame about to be enqueued
+rt_status acquire_feedback(rt_scene *sc, rt_scene::Feedback **out) {
+    rt_scene::Feedback &f = sc->feedback[sc->feedback_next];
+    sc->feedback_next = (sc->feedback_next + 1) % kFeedbackSlots;
+    if (f.pending) {                   // the caller is kFeedbackSlots frames ahead of the device: wait for the oldest
+        HIP_TRY(hipEventSynchronize(f.done));
+        f.pending = false;
+        if (const rt_status st = judge_frame(sc, f)) return st;
+    }
+    if (!f.host) {
+        HIP_TRY(hipHostMalloc((void **)&f.host, 2 * kMaxPasses * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipEventCreate(&f.start));
+        HIP_TRY(hipEventCreate(&f.done));
+    }
+    *out = &f;
+    return RT_OK;
+}
 // rt_render and rt_render_tile: whole rows of a shard, or a rectangle
 rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *shard, const Tile *tile, float *d_fb_sum, void *hip_stream,
                       int32_t sync, rt_timing *timing) {
@@ -552,10 +651,13 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     if (st != RT_OK) return st;
     if ((st = check_device(sc)) != RT_OK) return st;
     if (!d_fb_sum) return fail(RT_ERR_INVALID_ARG, "null framebuffer");
+    if ((st = timing_check(timing)) != RT_OK) return st;
     const rt_config &cfg = sc->cfg;
     hipStream_t stream = (hipStream_t)hip_stream;
     P.fb = d_fb_sum;
-    if (timing) std::memset(timing, 0, sizeof(*timing));
+    timing_out(rt_timing{}, timing);
+    // what earlier frames of this handle reported about their guarded walk (no wait: whatever has landed by now)
+    if ((st = poll_feedback(sc, false)) != RT_OK) return st;
     const size_t fb_bytes = (size_t)P.local_rows * P.row_w * 3 * sizeof(float);
     if (P.local_rows == 0) return RT_OK;
     if (P.spp <= 0 || P.max_depth <= 0) {     // the reference's loops add nothing: all-zero sums
@@ -593,6 +695,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     // ---- guarded near-first walk: only for eligible scenes that fit LDS with a useful stack
     bool guarded = sc->guard.ok && cfg.traversal != RT_TRAVERSAL_EXACT && P.root >= 0 && guarded_wanted(cfg, (int64_t)P.num_spheres + P.num_planes) &&
                    !(sc->guard_paused && !cfg.guard_keep);
+    // (AUTO only: one exact frame to time the guarded walk against — judge_frame)
+    const bool exploring = guarded && sc->explore_exact && cfg.traversal == RT_TRAVERSAL_AUTO && !cfg.guard_keep;
+    if (exploring) guarded = false;
     Shape fast{};
     // kernel form of the guarded pass: render_kernel (a lane owns a path) or render_kernel_wf (a wave owns a pool of paths)
     const bool want_wavefront = cfg.kernel == RT_KERNEL_WAVEFRONT;
@@ -606,6 +711,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
     // the sphere-only build of the octant walk (render_kernel<…, kSimple>): 1024-thread workgroups, 8 waves per SIMD
     bool simple = false;
+    uint32_t flag_stage = 0;       // words per wave of the LDS stage for flagged samples
     if (guarded) {
         // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
         // spheres for origins within sqrt(d0_sq) of their cluster: a camera outside either gets the tree re-packed
@@ -689,6 +795,14 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (!want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
                                     (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
+        // what is left of the workgroup's LDS share stages flagged samples per wave (render_kernel, flag_append): 32, 16 or 8 words
+        if (!want_wavefront) {
+            const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
+            const uint32_t gwaves = gblock / (uint32_t)rtk::kWave;
+            for (uint32_t words = 32u; words >= 8u && flag_stage == 0u; words >>= 1)
+                if ((uint64_t)fast.lds_bytes + (uint64_t)gwaves * words * 4u <= budget) flag_stage = words;
+            fast.lds_bytes += gwaves * flag_stage * 4u;
+        }
     }
     bool use_queue = false;
 #ifdef RTP_DEV_QUEUE_KERNEL
@@ -839,6 +953,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     P.cand = prim ? sc->cand : nullptr;
     P.order = prim ? sc->cand + sc->cand_pixels * rtk::kCandWords : nullptr;
     P.traced_pixels = prim ? P.order + sc->cand_pixels + 2 * (((size_t)num_pixels + rtk::kOrderBlock - 1) / rtk::kOrderBlock) : nullptr;      // counts[2 * blocks] after the scan
+    rt_scene::Feedback *feedback = nullptr;
+    if ((st = acquire_feedback(sc, &feedback)) != RT_OK) return st;
+    HIP_TRY(hipEventRecord(feedback->start, stream));
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
     if (prim) {
         const double coord_max = rtbeam::coord_bound(cam->origin.e, cam->pixel00_loc.e, cam->pixel_delta_u.e, cam->pixel_delta_v.e, cam->image_width, cam->image_height);
@@ -998,6 +1115,10 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             P.dirty_count = sc->queue + kQueueDirty + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
             if (const uint32_t tiny = cfg.flag_capacity) P.flag_cap = tiny < P.flag_cap ? tiny : P.flag_cap;   // test hook: overflow path
+            P.flag_stage = flag_stage;
+            // in-launch bail-out (not for a caller who insists on the guarded walk, nor for the experimental kernels)
+            P.bail_share = (cfg.guard_keep || wavefront) ? 0u : bail_share_of(cfg);
+            P.abandon = P.bail_share != 0u ? sc->queue + kQueueAbandon + pass : nullptr;
             rtk::fill_consts(P);          // (everything the constants block copies is final now)
             if (wavefront) {
                 P.wf_pool = sc->wf_pool;
@@ -1044,6 +1165,10 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
                 HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_fork, 0));
                 join_guard.forked = true;
                 launch_stream = sc->aux_stream;
+                // the pixels the trace launch marked, as a list for the second accumulate launch
+                hipLaunchKernelGGL(rtk::dirty_compact_kernel, dim3((num_pixels + rtk::kDirtyBlock - 1) / rtk::kDirtyBlock), dim3(rtk::kDirtyBlock), 0, sc->aux_stream,
+                                   (const uint32_t *)sc->dirty, num_pixels, sc->dirty_list, sc->queue + kQueueDirty + pass);
+                HIP_TRY(hipGetLastError());
             }
             HIP_TRY(launch_exact(R, grid_for(exact)));
             launch_stream = stream;
@@ -1059,14 +1184,22 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // … then added to the pixel sums strictly in sample order
         const dim3 acc_grid((num_pixels + 64 * rtk::kAccWaves - 1) / (64 * rtk::kAccWaves)), acc_block(64 * rtk::kAccWaves);
         if (overlapped) {
+            // (a pass the guarded launch gave up has rows nobody traced yet: both launches stand down — P.abandon — and a third one,
+            // after the re-walk of everything, sums every pixel)
             hipLaunchKernelGGL(rtk::accumulate_kernel<true>, acc_grid, acc_block, 0, sc->aux_stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
-                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)sc->dirty_list, (const uint32_t *)(sc->queue + kQueueDirty + pass));
+                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)sc->dirty_list, (const uint32_t *)(sc->queue + kQueueDirty + pass),
+                               (const uint32_t *)nullptr, 0u, 0.0f, 0.0f, 0.0f, (const uint32_t *)P.abandon, 0u);
             HIP_TRY(hipEventRecord(sc->ev_join, sc->aux_stream));
             // … while every other pixel is accumulated here
             hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
-                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)nullptr, (const uint32_t *)nullptr, P.cand, (uint32_t)rtk::kCandWords, P.bg[0], P.bg[1], P.bg[2]);
+                               P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)nullptr, (const uint32_t *)nullptr, P.cand, (uint32_t)rtk::kCandWords, P.bg[0], P.bg[1], P.bg[2],
+                               (const uint32_t *)P.abandon, 0u);
             HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join, 0));
             join_guard.forked = false;
+            if (P.abandon)
+                hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
+                                   P.pass_count, pass == 0 ? 1 : 0, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, P.cand, (uint32_t)rtk::kCandWords,
+                                   P.bg[0], P.bg[1], P.bg[2], (const uint32_t *)P.abandon, 1u);
         } else {
             hipLaunchKernelGGL(rtk::accumulate_kernel<false>, acc_grid, acc_block, 0, stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
                                P.pass_count, pass == 0 ? 1 : 0, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, P.cand, (uint32_t)rtk::kCandWords, P.bg[0], P.bg[1], P.bg[2]);
@@ -1074,6 +1207,20 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->ev_stop, stream));
+    {
+        // flagged counts and abandon words of this call → pinned host memory, and the frame's end, for a later call's poll_feedback
+        rt_scene::Feedback &f = *feedback;
+        if (guarded) {
+            HIP_TRY(hipMemcpyAsync(f.host, sc->queue + kQueueFlag, (size_t)passes * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(f.host + kMaxPasses, sc->queue + kQueueAbandon, (size_t)passes * 4, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(hipEventRecord(f.done, stream));
+        f.pending = true;
+        f.guarded = guarded;
+        f.exploring = exploring;
+        f.passes = passes;
+        f.samples = (uint64_t)num_pixels * (uint64_t)P.spp;
+    }
     sc->timed = true;
     sc->last = rt_timing{};
     sc->last.num_workgroups = (uint32_t)wgs;
@@ -1097,7 +1244,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
     if (sync) return rt_last_timing(sc, timing);
-    if (timing) *timing = sc->last;
+    timing_out(sc->last, timing);
     return RT_OK;
 }
 }  // namespace
@@ -1115,8 +1262,15 @@ rt_status rt_render_tile(rt_scene *sc, const rt_camera_data *cam, int32_t tile_x
     return render_impl(sc, cam, nullptr, &tile, d_fb_sum, hip_stream, sync, timing);
 }
 
+void rt_timing_init(rt_timing *t) {
+    if (!t) return;
+    std::memset(t, 0, sizeof(*t));
+    t->struct_bytes = (uint32_t)sizeof(*t);
+}
+
 rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
     if (!sc) return fail(RT_ERR_INVALID_ARG, "null argument");
+    if (const rt_status ts = timing_check(timing)) return ts;
     if (sc->timed) {
         HIP_TRY(hipEventSynchronize(sc->ev_stop));
         HIP_TRY(hipEventElapsedTime(&sc->last.kernel_ms, sc->ev_start, sc->ev_stop));
@@ -1143,20 +1297,24 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
         sc->last.rework_ms = rework;
         sc->last.primary_ms = sc->last.primary_visibility ? primary : 0.0f;
         if (sc->last.guarded) {
-            std::vector<uint32_t> counts((size_t)sc->last_passes);
+            std::vector<uint32_t> counts((size_t)sc->last_passes), gave_up((size_t)sc->last_passes);
             HIP_TRY(hipMemcpy(counts.data(), sc->queue + kQueueFlag, counts.size() * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(gave_up.data(), sc->queue + kQueueAbandon, gave_up.size() * 4, hipMemcpyDeviceToHost));
             uint64_t total = 0;
-            for (uint32_t c : counts) total += c;
+            uint32_t abandoned = 0;
+            for (size_t p = 0; p < counts.size(); ++p) { total += counts[p]; abandoned += gave_up[p] != 0u ? 1u : 0u; }
             sc->last.flagged_samples = total;
-            // a scene the guarded walk keeps handing back (dense overlaps, a camera inside a sphere, …) is cheaper on the
-            // exact walk alone: later frames of this handle use it
-            if (total * 50 > sc->last_samples) sc->guard_paused = true;       // more than 2 % of the samples
+            sc->last.abandoned_passes = abandoned;
         }
+        // (the frame is done, so what it left for the handle's judgement has landed as well: a scene the guarded walk keeps handing
+        // back — dense overlaps, a camera inside a sphere, … — is cheaper on the exact walk alone; later frames of this handle use it)
+        if (const rt_status ps = poll_feedback(sc, true)) return ps;
+        sc->last.guard_paused = sc->guard_paused ? 1u : 0u;
         uint32_t abort_code = 0;
         HIP_TRY(hipMemcpy(&abort_code, sc->queue + kQueueStats + 15, 4, hipMemcpyDeviceToHost));
         if (abort_code != 0) return fail(RT_ERR_HIP, "render kernel aborted (protocol timeout, code " + std::to_string(abort_code) + ")");
     }
-    if (timing) *timing = sc->last;
+    timing_out(sc->last, timing);
     return RT_OK;
 }
 

@@ -314,12 +314,18 @@ rt_status rt_render_sharded(rt_context *ctx, const rt_camera_data *cam, int32_t 
     }
     const rt_status st = rt_gather(ctx, cam->image_width, cam->image_height, band_rows, d_fb_sum_root);
     if (st != RT_OK) return st;
-    if (timings)
+    if (timings) {
+        // (an array of the CALLER's rt_timing: its first element says how far apart the elements are)
+        const uint32_t stride = timings[0].struct_bytes;
+        if (stride < 8) return mfail(RT_ERR_INVALID_ARG, "rt_timing.struct_bytes is not set (rt_timing_init)");
         for (int r = 0; r < n; ++r) {
             MHIP(hipSetDevice(ctx->devices[(size_t)r]));
-            const rt_status ts = rt_last_timing(ctx->scenes[(size_t)r], &timings[r]);
+            rt_timing *slot = reinterpret_cast<rt_timing *>(reinterpret_cast<char *>(timings) + (size_t)r * stride);
+            slot->struct_bytes = stride;
+            const rt_status ts = rt_last_timing(ctx->scenes[(size_t)r], slot);
             if (ts != RT_OK) return mfail(ts, rt_get_last_error_string());
         }
+    }
     MHIP(hipSetDevice(ctx->devices[0]));
     return RT_OK;
 }

@@ -34,6 +34,7 @@ rt_scene *bound_scene() { return g_bound_scene; }
 void Camera::render(float *d_fb) const {
     const size_t num_pixels = static_cast<size_t>(image_width) * image_height;
     const rt_camera_data cam = build_camera_data();  // cudaMemcpyToSymbol(d_cam_data_const), src/camera.cu:324-325
+    rt_timing_init(&last_timing);
     RTP_CHECK(rt_render(bound_scene(), &cam, nullptr, d_fb, nullptr, 1, &last_timing));
 
     std::vector<float> host_fb(num_pixels * 3);
@@ -153,7 +154,8 @@ void gpu_render_pipelined(const SceneParams &params, const rt_scene_desc &desc, 
             const rt_camera_data cam = camera.build_camera_data();
 
             const auto t0 = std::chrono::steady_clock::now();
-            rt_timing timing{};
+            rt_timing timing;
+            rt_timing_init(&timing);
             RTP_CHECK(rt_render(scene, &cam, nullptr, d_fb, nullptr, 1, &timing));
             RTP_CHECK(rt_tonemap(d_fb, d_rgb, static_cast<int64_t>(num_pixels) * 3, params.sqrt_spp, nullptr));
             auto file = std::make_shared<PendingFile>();
@@ -210,6 +212,7 @@ void gpu_render_sharded(const SceneParams &params, const rt_scene_desc &desc, in
     RTP_CHECK(rt_device_alloc(num_pixels * 3, reinterpret_cast<void **>(&d_rgb)));
     std::thread writer;
     std::vector<rt_timing> timings(static_cast<size_t>(n));
+    for (rt_timing &t : timings) rt_timing_init(&t);
     for (int f = 0; f < params.num_frames; ++f) {
         const std::string filename = frame_filename(params.output_pattern, f);
         Vec3 eye, target;

@@ -59,12 +59,18 @@ class Shard(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("kernel_ms", C.c_float), ("num_workgroups", C.c_uint32), ("workgroup_size", C.c_uint32),
+    """rt_timing (include/rtp_amd.h): an out-structure of the caller's size — struct_bytes is set on construction."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("kernel_ms", C.c_float), ("num_workgroups", C.c_uint32), ("workgroup_size", C.c_uint32),
                 ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("trace_launches", C.c_uint32),
                 ("trace_ms", C.c_float), ("guarded", C.c_uint32), ("flagged_samples", C.c_uint64), ("rework_ms", C.c_float),
                 ("guard_unproven", C.c_uint32), ("kernel", C.c_uint32), ("guard_dynamic", C.c_uint32), ("wide_nodes", C.c_uint32),
                 ("sphere_only", C.c_uint32), ("primary_visibility", C.c_uint32), ("primary_ms", C.c_float),
-                ("trace_vgprs", C.c_uint32), ("trace_scratch_bytes", C.c_uint32)]
+                ("trace_vgprs", C.c_uint32), ("trace_scratch_bytes", C.c_uint32), ("abandoned_passes", C.c_uint32),
+                ("guard_paused", C.c_uint32)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_bytes = C.sizeof(Timing)
 
 
 TRAVERSAL_AUTO, TRAVERSAL_EXACT, TRAVERSAL_GUARDED = 0, 1, 2
@@ -81,7 +87,8 @@ class Config(C.Structure):
                 ("lds_treelet", C.c_int32), ("workgroups_per_cu", C.c_int32), ("k_inner", C.c_int32), ("k_shade", C.c_int32),
                 ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
                 ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32),
-                ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32), ("primary_visibility", C.c_int32)]
+                ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32), ("primary_visibility", C.c_int32),
+                ("guard_bail_share", C.c_int32)]
 
 
 class ConfigInfo(C.Structure):
@@ -96,7 +103,7 @@ assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
 RTP_AMD_SYMBOLS = [
     "rt_set_device", "rt_scene_create", "rt_scene_create_ex", "rt_config_init", "rt_config_from_env", "rt_scene_set_config",
     "rt_scene_get_config", "rt_scene_destroy", "rt_scene_guard_reason", "rt_shard_rows", "rt_render", "rt_render_tile", "rt_last_kernel_ms",
-    "rt_last_timing",
+    "rt_last_timing", "rt_timing_init",
     "rt_render_to_host", "rt_trace_samples", "rt_closest_hits", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
     "rt_get_last_error_string", "rt_version_string",
     "rt_context_create", "rt_context_destroy", "rt_context_num_devices", "rt_context_transport", "rt_context_scene_create",
@@ -164,6 +171,8 @@ def amd_lib():
                                        C.c_int32, C.POINTER(Timing)]
         lib.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         lib.rt_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        lib.rt_timing_init.argtypes = [C.POINTER(Timing)]
+        lib.rt_timing_init.restype = None
         lib.rt_render_to_host.argtypes = [C.c_void_p, C.POINTER(CameraData), C.POINTER(Shard), C.c_void_p,
                                           C.POINTER(Timing)]
         lib.rt_trace_samples.argtypes = [C.c_void_p, C.POINTER(CameraData), C.c_int32, C.c_void_p, C.c_void_p,
@@ -443,6 +452,8 @@ class Context:
     def render(self, cam, d_fb_ptr, band_rows=8):
         """d_fb_ptr: device address on the root device of image_height*image_width*3 floats.  Returns the per-device timings."""
         t = (Timing * self.num_devices)()
+        for k in range(self.num_devices):
+            t[k].struct_bytes = C.sizeof(Timing)
         _check(amd_lib().rt_render_sharded(self._h, C.byref(cam), band_rows, C.c_void_p(d_fb_ptr), t), "rt_render_sharded")
         return list(t)
 

@@ -37,6 +37,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def run_child(cmd, timeout, **kw):
+    """A child process that uses the GPU, ended WITH ITS WHOLE GROUP when it overruns: the per-test limit above ends this
+    process with os._exit, and children left behind would keep holding the card.  `timeout` stays below that limit."""
+    import signal
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True, **kw)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        raise AssertionError(f"{cmd[0]} … did not finish within {timeout} s\n{out[-2000:]}\n{err[-2000:]}")
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def built_libraries():
     """Make sure the in-tree libraries exist (they are git-ignored build products)."""

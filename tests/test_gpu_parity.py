@@ -546,8 +546,8 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(RTP_BENCH_BACKEND="gloo", RTP_BENCH_CHECK="1")
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                         env=env, capture_output=True, text=True, timeout=900)
+    from conftest import run_child
+    res = run_child([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], 200, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout
@@ -589,6 +589,48 @@ def test_distance_aware_margins():
     fb, t = dev.render_to_host(cam)
     assert t.guarded == 1 and t.guard_dynamic == 1
     assert_same_frame(fb, ob.render(host, cam, threads=8), "scattered tiny spheres, distance-aware margins")
+
+
+def test_distance_aware_margins_with_the_by_pixel_primary_pass():
+    """the combination a big scene rendered in few big passes takes by default — distance-aware margins (kDyn
+    kernels) x the primary-visibility pass in its by-pixel form (primary_pixel_kernel: passes of 128 samples per pixel or more),
+    with and without planes — against the oracle on whole small frames: S-rtiow with the margins forced, 3 000 tiny spheres
+    spread wide (alone, and with quads, ellipses and triangles among them), and a 130-spp row band of S-100k."""
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=2)
+    cam = rb.rtiow_camera(96, 54, 130, 50)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.guard_dynamic == 1 and t.primary_visibility == 1 and t.trace_launches == 1 and t.abandoned_passes == 0
+    assert_same_frame(fb, ob.render(host, cam, threads=8), "S-rtiow, distance-aware margins, 130 spp in one pass")
+    rng = np.random.default_rng(777)
+    mats = [_material(0, albedo=(0.8, 0.7, 0.6)), _material(1, albedo=(0.9, 0.9, 0.8), fuzz=0.05), _material(2, ir=1.5),
+            _material(3, emit=(2.0, 1.5, 1.0))]
+    n = 3000
+    spheres = np.zeros((n, 5), dtype=np.float32)
+    spheres[:, :3] = rng.uniform(-400, 400, (n, 3))
+    spheres[:, 3] = rng.uniform(0.02, 0.6, n)
+    spheres[:, 4] = rng.integers(0, 4, n)
+    spheres[0] = [0, 0, -2000, 1600, 0]
+    planes = np.zeros((24, 11), dtype=np.float32)
+    planes[:, :3] = rng.uniform(-300, 300, (24, 3))
+    planes[:, 3:6] = rng.uniform(-60, 60, (24, 3))
+    planes[:, 6:9] = rng.uniform(-60, 60, (24, 3))
+    planes[:, 9] = rng.integers(0, 4, 24)
+    planes[:, 10] = rng.integers(0, 3, 24)
+    cam = rb.make_camera(80, 48, 50.0, (300, -250, 120), (0, 0, 0), (0.6, 0.7, 0.9), 136, 30)
+    for pl, what in ((np.zeros((0, 11), np.float32), "spheres only"), (planes, "with planes")):
+        host = rb.HostScene.from_arrays(spheres, pl, mats)
+        dev = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=2, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
+        assert dev.guard_reason() == "", dev.guard_reason()
+        fb, t = dev.render_to_host(cam)
+        assert t.guarded == 1 and t.guard_dynamic == 1 and t.primary_visibility == 1 and t.trace_launches == 1, what
+        assert_same_frame(fb, ob.render(host, cam, threads=8), f"scattered tiny spheres {what}, 136 spp in one pass")
+    host = rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=256)
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    cam = rb.rtiow_camera(3840, 2160, 130, 50)
+    fb, t = dev.render_tile_to_host(cam, 0, 1300, 3840, 2)
+    assert t.scene_in_lds == 0 and t.guarded == 1 and t.guard_dynamic == 1 and t.primary_visibility == 1 and t.trace_launches == 1
+    assert_same_frame(fb, ob.render(host, cam, row0=1300, row1=1302, threads=16), "S-100k, rows 1300-1301 at 130 spp")
 
 
 def test_wide_nodes_give_the_same_frames(config_scene):
@@ -751,21 +793,110 @@ def test_guarded_scene_handles_are_independent_and_reusable():
     assert_same_frame(f2.cpu().numpy(), ob.render(b, cam, threads=8), "async scene b")
 
 
-def test_guarded_walk_steps_aside_when_it_keeps_flagging(rtiow):
-    """A handle whose frame flagged more than 2 % of its samples renders its next frames with the exact walk
-    alone (here provoked with a 2-entry stack); the frames are the same bits either way."""
+def test_guarded_walk_steps_aside_or_is_timed_when_it_flags(rtiow):
+    """What RT_TRAVERSAL_AUTO does with a guarded walk that keeps handing samples back; the frames are the same bits whichever
+    walk made them.  (a) A 2-entry stack on S-rtiow flags a third of the samples: the pass gives up in the launch, the exact
+    walk renders it, the handle steps aside.  (b) A scene that flags about 4 % (332 overlapping spheres): above 0.4 % the
+    handle MEASURES — the next frame is the exact walk's, and whichever cost less per sample stays.  A caller who forces a
+    walk gets that walk, no measuring."""
     host = rb.HostScene.rtiow()
     dev = rb.DeviceScene(host, device=0)
     cam = rb.rtiow_camera(240, 135, 8, 50)
     want = ob.render(host, cam, threads=8)
     dev.configure(stack_levels=2)
     fb, t = dev.render_to_host(cam)
-    assert t.guarded == 1 and t.flagged_samples * 50 > 240 * 135 * 8
-    assert_same_frame(fb, want, "heavily flagged frame")
+    assert t.guarded == 1 and t.abandoned_passes == 1 and t.guard_paused == 1, (t.flagged_samples, t.abandoned_passes)
+    assert_same_frame(fb, want, "frame whose guarded pass gave up")
     dev.configure(stack_levels=0)
     fb, t = dev.render_to_host(cam)
     assert t.guarded == 0 and t.flagged_samples == 0
     assert_same_frame(fb, want, "next frame, exact walk")
+
+    host, cam, n = _stress_scene(2, 14, 16, 640, 360)
+    assert n == 332
+    exact = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_EXACT)
+    want, _ = exact.render_to_host(cam)
+    assert_same_frame(want[100:104], ob.render(host, cam, row0=100, row1=104, threads=8), "exact walk against the oracle")
+    dev = rb.DeviceScene(host, device=0)
+    fb, t = dev.render_to_host(cam)
+    share = t.flagged_samples / (640 * 360 * 16)
+    assert t.guarded == 1 and t.abandoned_passes == 0 and t.guard_paused == 0 and 0.004 < share < 0.09, share
+    assert_same_frame(fb, want, "flagged frame")
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 0 and t.flagged_samples == 0, "the frame after it is the exact walk's (timed against the guarded one)"
+    assert_same_frame(fb, want, "measuring frame")
+    fb, t3 = dev.render_to_host(cam)
+    assert t3.guarded == (0 if t3.guard_paused else 1), "… and the faster walk stays"
+    assert_same_frame(fb, want, "third frame")
+    fb, t4 = dev.render_to_host(cam)
+    assert t4.guarded == t3.guarded, "no further measuring"
+    forced = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_GUARDED)
+    for k in range(3):
+        fb, t = forced.render_to_host(cam)
+        assert t.guarded == 1, "a forced walk is not second-guessed by timing"
+    assert_same_frame(fb, want, "forced guarded")
+
+
+def _stress_scene(seed, trial, spp, width, height):
+    """Scene `trial` of tools/guard_stress.py's sequence for `seed`."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import guard_stress
+    for k, sph, pl, mats, cam, spread in guard_stress.scenes(seed, trial + 1, spp, width, height):
+        if k == trial:
+            return rb.HostScene.from_arrays(sph, pl, mats), cam, sph.shape[0]
+
+
+def test_heavily_flagged_scene_costs_little_more_than_the_exact_walk():
+    """VERDICT r03 W3.  1468 overlapping spheres, 46 % of the samples flagged by the guarded walk: round 3 spent 250 ms where the
+    exact walk needs 16 (one atomic per flagged sample on one counter).  Now the flagged samples are staged per wave, and the
+    pass gives up in the launch once the flagged share of what has been handed out passes rt_config.guard_bail_share: the
+    exact walk renders the whole pass, the frame is the exact walk's bit for bit, and the handle steps aside for its next
+    frames WITHOUT anybody calling rt_last_timing."""
+    import torch
+    host, cam, n = _stress_scene(1, 8, 48, 1280, 720)
+    assert n == 1468
+    exact = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_EXACT)
+    exact.render_to_host(cam)
+    want, te = exact.render_to_host(cam)
+    exact_ms = min(te.kernel_ms, exact.render_to_host(cam)[1].kernel_ms)
+    rows = ob.render(host, cam, row0=300, row1=302, threads=8)
+    assert_same_frame(want[300:302], rows, "exact walk against the oracle")
+
+    kept = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)       # no bail-out: the walk's real flagged share
+    fb, tk = kept.render_to_host(cam)
+    assert tk.guarded == 1 and tk.abandoned_passes == 0 and tk.flagged_samples > 0.3 * 1280 * 720 * 48, tk.flagged_samples
+    assert_same_frame(fb, want, "guarded walk kept, every flagged sample re-walked from the staged list")
+    assert tk.kernel_ms < 4.0 * exact_ms, (tk.kernel_ms, exact_ms)          # (was 15 x)
+
+    dev = rb.DeviceScene(host, device=0)                                                 # the defaults
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1 and t.abandoned_passes == 1 and t.guard_paused == 1
+    assert_same_frame(fb, want, "abandoned pass")
+    assert t.kernel_ms <= 1.5 * exact_ms, (t.kernel_ms, exact_ms)
+    fb, t2 = dev.render_to_host(cam)
+    assert t2.guarded == 0
+    assert_same_frame(fb, want, "frame after the abandoned one")
+
+    # an asynchronous caller that never asks for timings: the second frame already runs on the exact walk
+    dev = rb.DeviceScene(host, device=0)
+    f = torch.zeros((720, 1280, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.Stream()
+    t = dev.render(cam, f.data_ptr(), stream=stream.cuda_stream, sync=False)
+    assert t.guarded == 1
+    stream.synchronize()
+    t = dev.render(cam, f.data_ptr(), stream=stream.cuda_stream, sync=False)
+    assert t.guarded == 0, "the handle read what the first frame left in host memory"
+    stream.synchronize()
+    assert_same_frame(f.cpu().numpy(), want, "asynchronous caller")
+    # … and one that queues frames without ever waiting: the judgement arrives a few frames late, never wrong
+    dev = rb.DeviceScene(host, device=0)
+    walks = []
+    for k in range(8):
+        walks.append(dev.render(cam, f.data_ptr(), stream=stream.cuda_stream, sync=False).guarded)
+    stream.synchronize()
+    assert walks[0] == 1 and walks[-1] == 0, walks
+    assert_same_frame(f.cpu().numpy(), want, "eight frames queued back to back")
 
 
 def test_guarded_walk_far_camera_and_ties(force_guarded):
@@ -910,7 +1041,7 @@ def test_stress_scene_whole_4k_frame():
     cam = rb.rtiow_camera(3840, 2160, 2, 50)
     want = ob.render(host, cam, threads=16)
     fb, t = dev.render_to_host(cam)
-    assert t.scene_in_lds == 0 and t.guarded == 1 and t.guard_unproven == 0 and t.guard_dynamic == 1
+    assert t.scene_in_lds == 0 and t.guarded == 1 and t.guard_unproven == 0 and t.guard_dynamic == 1 and t.primary_visibility == 1
     assert_same_frame(fb, want, "4K frame, guarded walk with distance-aware margins")
     dev.configure(traversal=rb.TRAVERSAL_EXACT)
     fb, t = dev.render_to_host(cam)
@@ -1070,7 +1201,7 @@ def test_developer_build_checks():
     dev_lib = os.path.join(os.path.dirname(HERE), "ray-tracing-practice_amd", "librtp_amd_dev.so")
     assert os.path.exists(dev_lib), "run __graft_entry__.build() (make -C ray-tracing-practice_amd dev)"
     env = dict(os.environ, RTP_AMD_LIB=dev_lib)
-    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "dev_build_checks.py"), "-x", "-q", "-p", "no:cacheprovider"],
-                         env=env, capture_output=True, text=True, timeout=1200)
+    from conftest import run_child
+    res = run_child([sys.executable, "-m", "pytest", os.path.join(HERE, "dev_build_checks.py"), "-x", "-q", "-p", "no:cacheprovider"], 200, env=env)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert " passed" in res.stdout and "failed" not in res.stdout

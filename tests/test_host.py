@@ -25,6 +25,18 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.rt_version_string()
 
 
+def test_timing_struct_is_sized_by_the_caller():
+    """rt_timing is an out-structure of the CALLER's size: rt_timing_init writes sizeof(rt_timing) as the library was compiled,
+    which is what the ctypes mirror holds; a call with struct_bytes unset is refused (no GPU needed for either)."""
+    lib = rb.amd_lib()
+    t = rb.Timing()
+    t.struct_bytes = 0
+    lib.rt_timing_init(C.byref(t))
+    assert t.struct_bytes == C.sizeof(rb.Timing)
+    t.struct_bytes = 0
+    assert lib.rt_last_timing(None, C.byref(t)) == 1          # RT_ERR_INVALID_ARG (null scene)
+
+
 def test_shard_rows_partition_the_image():
     lib = rb.amd_lib()
     for height in (1, 7, 64, 225, 1080):
@@ -171,7 +183,7 @@ def test_config_defaults_and_env_overlay():
     cfg = rb.Config()
     lib.rt_config_init(C.byref(cfg))
     assert cfg.struct_bytes == C.sizeof(rb.Config)
-    assert cfg.traversal == rb.TRAVERSAL_AUTO and cfg.guard_gamma_ulps == 0.0 and cfg.guard_min_primitives == 16
+    assert cfg.traversal == rb.TRAVERSAL_AUTO and cfg.guard_gamma_ulps == 0.0 and cfg.guard_min_primitives == 64
     assert cfg.guard_repack == 1 and cfg.scene_in_lds == 1 and cfg.lds_treelet == 1 and cfg.reserve_taper == 1
     assert cfg.workspace_bytes == 0          # auto: a sixteenth of the device's memory
     saved = {k: os.environ.get(k) for k in ("RTP_TRAVERSAL", "RTP_PASS_SPP", "RTP_GUARD_GAMMA_ULPS", "RTP_SLAB_GIB")}

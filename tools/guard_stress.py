@@ -1,11 +1,16 @@
-"""Developer tool (GPU): guarded walk vs exact walk (itself checked against the oracle by the test suite) on
-many random scenes at scale — sphere scenes of 20 to 3000 spheres with radii over three decades, with and without a
-huge ground sphere, mixed sphere/plane scenes, cameras inside, outside and far away.  Reports differing pixels."""
-import os, sys, time
+"""Developer tool (GPU): what a drop-in user gets by DEFAULT (rt_config as rt_config_init leaves it) against the exact walk
+(itself checked against the oracle by the test suite) on many random scenes at scale — sphere scenes of 20 to 3000 spheres
+with radii over three decades, with and without a huge ground sphere, mixed sphere/plane scenes, cameras inside, outside and
+far away.  Per scene: a fresh handle's FIRST default frame (the one that pays for finding out that a scene does not suit the
+guarded walk: in-launch bail-out), its second and third (after the handle's own judgement: step aside / one exact frame to time
+against), the exact walk, and a frame with the guarded walk forced.  Reports differing pixels and the default ÷ exact ratios."""
+import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ray-tracing-practice_amd"))
 import numpy as np
 import rtp_bindings as rb
-rb.HONOUR_ENV = True      # developer tool: RTP_* variables steer the handles made below
+
+W, H = 1280, 720
+
 
 def material(rng):
     m = rb.Material()
@@ -16,41 +21,67 @@ def material(rng):
     m.texture_id = 0
     return m
 
-rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
-N = int(os.environ.get("SCENES", "24"))
-W, H, SPP = 1280, 720, int(os.environ.get("SPP", "48"))
-total_bad = 0
-total_samples = 0
-for trial in range(N):
-    n = int(10 ** rng.uniform(1.3, 3.5))
-    mats = [material(rng) for _ in range(8)]
-    spread = float(rng.choice([2.0, 8.0, 30.0, 100.0]))
-    sph = np.zeros((n, 5), np.float32)
-    sph[:, :3] = rng.uniform(-spread, spread, (n, 3)) * np.array([1, 1, 0.3 if trial % 3 == 0 else 1.0])
-    sph[:, 3] = 10.0 ** rng.uniform(-2.3, np.log10(spread) - 0.8, n)
-    sph[:, 4] = rng.integers(0, len(mats), n)
-    if trial % 2 == 0:
-        sph[0] = (0, 0, -1000 - 0.3 * spread, 1000, 0)
-    n_pl = int(rng.integers(0, 60)) if trial % 4 == 1 else 0
-    pl = np.zeros((n_pl, 11), np.float32)
-    if n_pl:
-        pl[:, :3] = rng.uniform(-spread, spread, (n_pl, 3))
-        pl[:, 3:6] = rng.uniform(-0.3 * spread, 0.3 * spread, (n_pl, 3))
-        pl[:, 6:9] = rng.uniform(-0.3 * spread, 0.3 * spread, (n_pl, 3))
-        pl[:, 9] = rng.integers(0, len(mats), n_pl)
-        pl[:, 10] = rng.integers(0, 3, n_pl)
-    host = rb.HostScene.from_arrays(sph, pl, mats)
-    dev = rb.DeviceScene(host, 0)
-    eye = rng.uniform(-spread, spread, 3) * float(rng.choice([0.3, 1.0, 1.5, 6.0]))
-    cam = rb.make_camera(W, H, float(rng.uniform(15, 90)), eye, rng.uniform(-0.3 * spread, 0.3 * spread, 3), rng.uniform(0, 1, 3), SPP,
-                         int(rng.integers(2, 50)))
-    os.environ["RTP_TRAVERSAL"] = "guarded"
-    g, tg = dev.render_to_host(cam)
-    os.environ["RTP_TRAVERSAL"] = "threaded"
-    e, te = dev.render_to_host(cam)
-    bad = int((g.view(np.uint32) != e.view(np.uint32)).any(axis=-1).sum())
-    total_bad += bad
-    total_samples += W * H * SPP
-    print(f"scene {trial:2d}: {n:5d} spheres {n_pl:2d} planes spread {spread:5.1f} | guarded {tg.guarded} primary pass {tg.primary_visibility} ({dev.guard_reason() or 'eligible'}) "
-          f"flagged {100.0 * tg.flagged_samples / (W * H * SPP):7.4f} % | {tg.kernel_ms:7.2f} ms vs exact {te.kernel_ms:7.2f} ms | differing pixels {bad}", flush=True)
-print(f"TOTAL: {N} scenes, {total_samples / 1e9:.2f} G samples, differing pixels {total_bad}")
+
+def scenes(seed, count, spp=48, width=W, height=H):
+    """The scenes of one seed, in order: (trial, spheres [n,5], planes [m,11], materials, camera, spread)."""
+    rng = np.random.default_rng(seed)
+    for trial in range(count):
+        n = int(10 ** rng.uniform(1.3, 3.5))
+        mats = [material(rng) for _ in range(8)]
+        spread = float(rng.choice([2.0, 8.0, 30.0, 100.0]))
+        sph = np.zeros((n, 5), np.float32)
+        sph[:, :3] = rng.uniform(-spread, spread, (n, 3)) * np.array([1, 1, 0.3 if trial % 3 == 0 else 1.0])
+        sph[:, 3] = 10.0 ** rng.uniform(-2.3, np.log10(spread) - 0.8, n)
+        sph[:, 4] = rng.integers(0, len(mats), n)
+        if trial % 2 == 0:
+            sph[0] = (0, 0, -1000 - 0.3 * spread, 1000, 0)
+        n_pl = int(rng.integers(0, 60)) if trial % 4 == 1 else 0
+        pl = np.zeros((n_pl, 11), np.float32)
+        if n_pl:
+            pl[:, :3] = rng.uniform(-spread, spread, (n_pl, 3))
+            pl[:, 3:6] = rng.uniform(-0.3 * spread, 0.3 * spread, (n_pl, 3))
+            pl[:, 6:9] = rng.uniform(-0.3 * spread, 0.3 * spread, (n_pl, 3))
+            pl[:, 9] = rng.integers(0, len(mats), n_pl)
+            pl[:, 10] = rng.integers(0, 3, n_pl)
+        eye = rng.uniform(-spread, spread, 3) * float(rng.choice([0.3, 1.0, 1.5, 6.0]))
+        cam = rb.make_camera(width, height, float(rng.uniform(15, 90)), eye, rng.uniform(-0.3 * spread, 0.3 * spread, 3), rng.uniform(0, 1, 3), spp,
+                             int(rng.integers(2, 50)))
+        yield trial, sph, pl, mats, cam, spread
+
+
+def main():
+    seed, count, spp = int(os.environ.get("SEED", "1")), int(os.environ.get("SCENES", "24")), int(os.environ.get("SPP", "48"))
+    total_bad = total_samples = over = 0
+    worst = 0.0
+    for trial, sph, pl, mats, cam, spread in scenes(seed, count, spp):
+        host = rb.HostScene.from_arrays(sph, pl, mats)
+        n_samples = W * H * spp
+        exact = rb.DeviceScene(host, 0, traversal=rb.TRAVERSAL_EXACT)
+        exact.render_to_host(cam)                        # warm-up (code objects, clocks, the slab)
+        e, te = exact.render_to_host(cam)
+        exact.close()
+        dev = rb.DeviceScene(host, 0)                    # the defaults
+        frames = [dev.render_to_host(cam) for _ in range(3)]
+        dev.close()
+        forced = rb.DeviceScene(host, 0, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
+        g, tg = forced.render_to_host(cam)
+        reason = forced.guard_reason() or "eligible"
+        forced.close()
+        bad = sum(int((fb.view(np.uint32) != e.view(np.uint32)).any(axis=-1).sum()) for fb, _ in frames + [(g, tg)])
+        total_bad += bad
+        total_samples += n_samples
+        ratios = [t.kernel_ms / te.kernel_ms for _, t in frames]
+        worst = max(worst, *ratios)
+        over += sum(int(r > 1.3) for r in ratios)
+        t0 = frames[0][1]
+        print(f"scene {trial:2d}: {sph.shape[0]:5d} spheres {pl.shape[0]:2d} planes spread {spread:5.1f} ({reason}) | default frames: "
+              + ", ".join(f"{t.kernel_ms:7.2f} ms ({'guarded' if t.guarded else 'exact'}{', abandoned' if t.abandoned_passes else ''})" for _, t in frames)
+              + f" | flagged {100.0 * t0.flagged_samples / n_samples:7.4f} % trace {t0.trace_ms:6.2f} re-walk {t0.rework_ms:6.2f} primary {t0.primary_ms:5.2f} | exact {te.kernel_ms:7.2f} ms"
+              f" | forced guarded {tg.kernel_ms:7.2f} ms, flagged {100.0 * tg.flagged_samples / n_samples:7.4f} % | ratios " + " ".join(f"{r:4.2f}" for r in ratios)
+              + ("  <-- above 1.3" if max(ratios) > 1.3 else "") + f" | differing pixels {bad}", flush=True)
+    print(f"TOTAL seed {seed}: {count} scenes, {total_samples / 1e9:.2f} G samples per frame set, differing pixels {total_bad}, worst default/exact ratio {worst:.2f}, "
+          f"default frames above 1.3: {over}")
+
+
+if __name__ == "__main__":
+    main()
