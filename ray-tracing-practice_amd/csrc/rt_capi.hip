@@ -75,8 +75,9 @@ constexpr int kQueueWords = 5 * kMaxPasses + 16;
 // to pinned host memory at the end of the call, with an event — the handle's decision to step aside from the guarded walk needs no
 // rt_last_timing and no synchronisation of the caller's.
 constexpr int kFeedbackSlots = 4;
-constexpr uint32_t kDefaultBailShare = 24;            // of 256: 9.4 % (rt_config.guard_bail_share)
-constexpr uint32_t kExploreShare = 1;                 // of 256: a guarded frame that flagged more than 0.4 % is timed against an exact one
+constexpr uint32_t kDefaultBailShare = 64;            // of 256: 25 % (rt_config.guard_bail_share)
+constexpr uint32_t kExploreShare = 1;                 // of 256: a guarded frame that flagged more than 0.4 % is timed against an exact one …
+constexpr float kExploreOverhead = 0.15f;             // … and so is one that spent more than this share of its time outside the trace launch
 
 // Traversal (rt_config.traversal).  EXACT ("threaded"): the caller's tree in the reference's own visit order — the
 // result is the reference's by construction.  GUARDED (AUTO's choice where the scene is eligible): near-first walk
@@ -177,7 +178,7 @@ struct rt_scene {
     struct Feedback {
         uint32_t *host = nullptr; hipEvent_t start = nullptr, done = nullptr;
         bool pending = false, guarded = false, exploring = false;
-        int passes = 0; uint64_t samples = 0;
+        int passes = 0; uint64_t samples = 0, serial = 0;
     };
     Feedback feedback[kFeedbackSlots];
     int feedback_next = 0;
@@ -185,6 +186,7 @@ struct rt_scene {
     // handle render ONE frame with the exact walk and keep whichever was faster per sample (judge_frame)
     double guarded_ns_per_sample = 0.0, exact_ns_per_sample = 0.0;
     bool explore_exact = false;
+    uint64_t frame_serial = 0;      // render calls so far (a feedback slot knows which one it belongs to)
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
@@ -593,6 +595,28 @@ namespace {
 // and event times): a pass that gave up, or more flagged samples overall than the bail share, and the following frames go to the
 // exact walk; a frame that flagged more than kExploreShare makes the next AUTO frame an exact one, and the faster of the two per
 // sample stays (rt_config.guard_keep: the guarded walk stays whatever happens).
+// trace / re-walk / primary-pass time of the handle's most recent frame, from its per-pass events (the frame must be done)
+rt_status frame_parts(rt_scene *sc, float &trace, float &rework, float &primary) {
+    trace = rework = primary = 0.0f;
+    for (int p = 0; p < sc->timed_passes; ++p) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p], sc->pass_events[4 * p + 1]));
+        primary += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p + 1], sc->pass_events[4 * p + 2]));
+        trace += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p + 2], sc->pass_events[4 * p + 3]));
+        rework += ms;
+    }
+    // passes beyond the individually timed ones are priced at the mean of the timed ones
+    if (sc->timed_passes > 0) {
+        const float scale = (float)sc->last.trace_launches / (float)sc->timed_passes;
+        trace *= scale; rework *= scale; primary *= scale;
+        float ms = 0.0f;          // + the per-pixel candidate lists, made once per call before the first pass
+        HIP_TRY(hipEventElapsedTime(&ms, sc->ev_start, sc->pass_events[0]));
+        primary += ms;
+    }
+    return RT_OK;
+}
 rt_status judge_frame(rt_scene *sc, rt_scene::Feedback &f) {
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, f.start, f.done));
@@ -604,7 +628,15 @@ rt_status judge_frame(rt_scene *sc, rt_scene::Feedback &f) {
         for (int p = 0; p < f.passes; ++p) { total += f.host[p]; gave_up += f.host[kMaxPasses + p] != 0u ? 1u : 0u; }
         if (share != 0u && (gave_up != 0u || total * 256u > (uint64_t)share * f.samples)) sc->guard_paused = true;
         if (gave_up == 0u) sc->guarded_ns_per_sample = ns;
-        if (share != 0u && !sc->guard_paused && sc->exact_ns_per_sample == 0.0 && total * 256u > (uint64_t)kExploreShare * f.samples) sc->explore_exact = true;
+        // worth a measurement?  many flagged samples, or much time spent on what the exact walk does not need (the primary pass,
+        // the re-walk launch) — the guarded trace launch would have to be faster by that much just to draw level
+        bool doubt = total * 256u > (uint64_t)kExploreShare * f.samples;
+        if (!doubt && f.serial == sc->frame_serial && sc->timed) {       // (the per-pass events are this frame's: nothing was enqueued after it)
+            float trace = 0.0f, rework = 0.0f, primary = 0.0f;
+            if (const rt_status st = frame_parts(sc, trace, rework, primary)) return st;
+            doubt = rework + primary > kExploreOverhead * ms;
+        }
+        if (share != 0u && !sc->guard_paused && sc->exact_ns_per_sample == 0.0 && doubt) sc->explore_exact = true;
     } else if (f.exploring) {
         sc->exact_ns_per_sample = ns;
         sc->explore_exact = false;
@@ -1158,6 +1190,14 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             R.work_cap = P.flag_cap;
             R.chunk = 64u;                     // a short list: finest granularity
             R.taper_shift = 0;
+            {       // … unless it turns out to be the whole pass (overflow, abandoned guarded pass): a trace launch's reservations
+                const uint64_t waves_total = (uint64_t)grid_for(exact) * (rtk::kBlock / rtk::kWave);
+                uint64_t per = (uint64_t)P.total_work / (waves_total * 16u * 64u);
+                per = per < 1 ? 1 : (per > 16 ? 16 : per);
+                R.full_chunk = (uint32_t)(64u * per);
+                R.full_taper = 1;
+                while (((uint64_t)1 << R.full_taper) < RTP_TAPER_FACTOR * waves_total) ++R.full_taper;
+            }
             R.dirty = nullptr;
             if (overlap) {
                 // the re-walk and the accumulation of the pixels it touches on the second stream …
@@ -1220,6 +1260,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         f.exploring = exploring;
         f.passes = passes;
         f.samples = (uint64_t)num_pixels * (uint64_t)P.spp;
+        f.serial = ++sc->frame_serial;
     }
     sc->timed = true;
     sc->last = rt_timing{};
@@ -1275,24 +1316,7 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
         HIP_TRY(hipEventSynchronize(sc->ev_stop));
         HIP_TRY(hipEventElapsedTime(&sc->last.kernel_ms, sc->ev_start, sc->ev_stop));
         float sum = 0.0f, rework = 0.0f, primary = 0.0f;
-        for (int p = 0; p < sc->timed_passes; ++p) {
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p], sc->pass_events[4 * p + 1]));
-            primary += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p + 1], sc->pass_events[4 * p + 2]));
-            sum += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, sc->pass_events[4 * p + 2], sc->pass_events[4 * p + 3]));
-            rework += ms;
-        }
-        // passes beyond the individually timed ones are priced at the mean of the timed ones
-        if (sc->timed_passes > 0) {
-            sum *= (float)sc->last.trace_launches / (float)sc->timed_passes;
-            rework *= (float)sc->last.trace_launches / (float)sc->timed_passes;
-            primary *= (float)sc->last.trace_launches / (float)sc->timed_passes;
-            float ms = 0.0f;          // + the per-pixel candidate lists, made once per call before the first pass
-            HIP_TRY(hipEventElapsedTime(&ms, sc->ev_start, sc->pass_events[0]));
-            primary += ms;
-        }
+        if (const rt_status ps = frame_parts(sc, sum, rework, primary)) return ps;
         sc->last.trace_ms = sum;
         sc->last.rework_ms = rework;
         sc->last.primary_ms = sc->last.primary_visibility ? primary : 0.0f;

@@ -29,14 +29,24 @@ def assert_same_frame(got, want, what):
     assert same.all(), f"{what}: {(~same).sum()} of {same.size} pixels differ, max abs diff {np.abs(got - want).max()}"
 
 
+# Handles in this module render many frames each: unless a test says otherwise they ask for the guarded walk outright (where the
+# scene is eligible) and keep it, so that which walk a frame took does not depend on what the handle has measured or flagged on
+# its earlier frames.  The policy has its own tests, on handles made with traversal=rb.TRAVERSAL_AUTO — what rt_config_init gives.
+@pytest.fixture(scope="module", autouse=True)
+def guarded_walk_by_default():
+    rb.DEFAULTS.update(traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
+    yield
+    rb.DEFAULTS.clear()
+
+
 @pytest.fixture(scope="module")
-def rtiow():
+def rtiow(guarded_walk_by_default):
     host = rb.HostScene.rtiow()
     return host, rb.DeviceScene(host, device=0)
 
 
 @pytest.fixture(scope="module")
-def config_scene(test_config_text):
+def config_scene(test_config_text, guarded_walk_by_default):
     host = rb.HostScene.from_config(test_config_text)
     return host, rb.DeviceScene(host, device=0)
 
@@ -108,12 +118,99 @@ def test_rtiow_c2_rows_at_full_width(rtiow):
         assert_same_frame(fb[row0:row0 + 20], want, f"rows {row0}..")
 
 
+def test_rtiow_probe_at_headline_config(rtiow):
+    host, dev = rtiow
+    g = np.load(os.path.join(HERE, "golden", "rtiow_probe.npz"))
+    cam = rb.rtiow_camera(1920, 1080, 500, 50)
+    rad, rays, seeds = dev.trace_samples(cam, g["ijs"])
+    assert np.array_equal(bits(rad), g["rad_bits"])
+    assert np.array_equal(rays, g["rays"]) and np.array_equal(seeds, g["seeds"])
+    assert rays.max() > 20        # deep paths are exercised
+
+
+def test_rtiow_small_frame_matches_golden(rtiow):
+    host, dev = rtiow
+    g = np.load(os.path.join(HERE, "golden", "rtiow_probe.npz"))
+    fb, t = dev.render_to_host(rb.rtiow_camera(96, 64, 4, 50))
+    assert np.array_equal(bits(fb), g["fb_bits"])
+    assert t.scene_in_lds == 1 and t.kernel_ms > 0
+
+
+def test_rtiow_c2_rows_at_full_width(rtiow):
+    """BASELINE configs[1] geometry (1200x800, depth 50) at 6 spp: every pixel of the GPU frame
+    equals the oracle's, checked on three row bands the oracle finishes in seconds."""
+    host, dev = rtiow
+    cam = rb.rtiow_camera(1200, 800, 6, 50)
+    fb, _ = dev.render_to_host(cam)
+    for row0 in (0, 396, 780):
+        want = ob.render(host, cam, row0=row0, row1=row0 + 20, threads=8)
+        assert_same_frame(fb[row0:row0 + 20], want, f"rows {row0}..")
+
+
+def test_rtiow_probe_at_headline_config(rtiow):
+    host, dev = rtiow
+    g = np.load(os.path.join(HERE, "golden", "rtiow_probe.npz"))
+    cam = rb.rtiow_camera(1920, 1080, 500, 50)
+    rad, rays, seeds = dev.trace_samples(cam, g["ijs"])
+    assert np.array_equal(bits(rad), g["rad_bits"])
+    assert np.array_equal(rays, g["rays"]) and np.array_equal(seeds, g["seeds"])
+    assert rays.max() > 20        # deep paths are exercised
+
+
+def test_rtiow_small_frame_matches_golden(rtiow):
+    host, dev = rtiow
+    g = np.load(os.path.join(HERE, "golden", "rtiow_probe.npz"))
+    fb, t = dev.render_to_host(rb.rtiow_camera(96, 64, 4, 50))
+    assert np.array_equal(bits(fb), g["fb_bits"])
+    assert t.scene_in_lds == 1 and t.kernel_ms > 0
+
+
+def test_rtiow_c2_rows_at_full_width(rtiow):
+    """BASELINE configs[1] geometry (1200x800, depth 50) at 6 spp: every pixel of the GPU frame
+    equals the oracle's, checked on three row bands the oracle finishes in seconds."""
+    host, dev = rtiow
+    cam = rb.rtiow_camera(1200, 800, 6, 50)
+    fb, _ = dev.render_to_host(cam)
+    for row0 in (0, 396, 780):
+        want = ob.render(host, cam, row0=row0, row1=row0 + 20, threads=8)
+        assert_same_frame(fb[row0:row0 + 20], want, f"rows {row0}..")
+
+
+def test_rtiow_probe_at_headline_config(rtiow):
+    host, dev = rtiow
+    g = np.load(os.path.join(HERE, "golden", "rtiow_probe.npz"))
+    cam = rb.rtiow_camera(1920, 1080, 500, 50)
+    rad, rays, seeds = dev.trace_samples(cam, g["ijs"])
+    assert np.array_equal(bits(rad), g["rad_bits"])
+    assert np.array_equal(rays, g["rays"]) and np.array_equal(seeds, g["seeds"])
+    assert rays.max() > 20        # deep paths are exercised
+
+
+def test_rtiow_small_frame_matches_golden(rtiow):
+    host, dev = rtiow
+    g = np.load(os.path.join(HERE, "golden", "rtiow_probe.npz"))
+    fb, t = dev.render_to_host(rb.rtiow_camera(96, 64, 4, 50))
+    assert np.array_equal(bits(fb), g["fb_bits"])
+    assert t.scene_in_lds == 1 and t.kernel_ms > 0
+
+
+def test_rtiow_c2_rows_at_full_width(rtiow):
+    """BASELINE configs[1] geometry (1200x800, depth 50) at 6 spp: every pixel of the GPU frame
+    equals the oracle's, checked on three row bands the oracle finishes in seconds."""
+    host, dev = rtiow
+    cam = rb.rtiow_camera(1200, 800, 6, 50)
+    fb, _ = dev.render_to_host(cam)
+    for row0 in (0, 396, 780):
+        want = ob.render(host, cam, row0=row0, row1=row0 + 20, threads=8)
+        assert_same_frame(fb[row0:row0 + 20], want, f"rows {row0}..")
+
+
 def test_production_kernel_at_the_headline_config():
     """BASELINE configs[2] — 1920x1080, 500 spp, 50 bounces — through the DEFAULT path of a fresh handle: ONE launch of the
     sphere-only trace kernel fed by the primary-visibility pass (render_kernel, src/camera.cu:17-34), three rows of the frame
     compared bit for bit with the oracle."""
     host = rb.HostScene.rtiow()
-    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    dev = rb.DeviceScene(host, device=0, honour_env=False, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)      # what rt_config_init gives
     cam = rb.rtiow_camera(1920, 1080, 500, 50)
     fb, t = dev.render_to_host(cam)
     assert t.guarded == 1 and t.sphere_only == 1 and t.primary_visibility == 1 and t.trace_launches == 1 and t.scene_in_lds == 1
@@ -128,7 +225,7 @@ def test_production_kernel_at_the_headline_config():
 def test_rtiow_c2_at_full_spp():
     """BASELINE configs[1] at its full 1200x800 x 100 spp x 50 bounces through the default path; two rows against the oracle."""
     host = rb.HostScene.rtiow()
-    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    dev = rb.DeviceScene(host, device=0, honour_env=False, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)      # what rt_config_init gives
     cam = rb.rtiow_camera(1200, 800, 100, 50)
     fb, t = dev.render_to_host(cam)
     assert t.guarded == 1 and t.sphere_only == 1 and t.primary_visibility == 1 and t.trace_launches == 1
@@ -144,7 +241,7 @@ def test_primary_visibility_pass_changes_nothing_but_the_time(config_scene):
     passes shorter and longer than a wave (the pass per batch and the pass per pixel), with several passes per frame, on a
     row shard, and where most pixels have no list at all (fat pixels: more candidates than a list holds)."""
     host = rb.HostScene.rtiow()
-    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    dev = rb.DeviceScene(host, device=0, honour_env=False, traversal=rb.TRAVERSAL_GUARDED)
     cases = [(rb.rtiow_camera(160, 90, 9, 50), {}, None), (rb.rtiow_camera(96, 54, 200, 50), {}, None),
              (rb.rtiow_camera(64, 36, 300, 50), {"pass_spp": 150}, None), (rb.rtiow_camera(64, 36, 200, 50), {"pass_spp": 64}, None),
              (rb.rtiow_camera(128, 72, 130, 50), {}, rb.Shard(8, 3, 1)), (rb.make_camera(16, 9, 90.0, (13, 3, 2), (0, 0, 0), (0.7, 0.8, 1.0), 130, 50), {}, None),
@@ -171,7 +268,7 @@ def test_primary_visibility_pass_changes_nothing_but_the_time(config_scene):
         a, ta = devc.render_to_host(cam)
         devc.configure(primary_visibility=-1)
         b, tb = devc.render_to_host(cam)
-        devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_AUTO)
+        devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_GUARDED)
         assert ta.primary_visibility == 1 and ta.sphere_only == 0 and tb.primary_visibility == 0
         assert_same_frame(a, b, f"config scene {spp} spp")
         if spp == 9:
@@ -220,7 +317,7 @@ def test_sky_pixels_and_the_fetch_order(config_scene):
     cam = rb.make_camera(120, 68, 100.0, eye, (0.0, 0.0, 4.5), (0.1, 0.2, 0.3), 130, 10)
     devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_GUARDED)
     fb, t = devc.render_to_host(cam)
-    devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_AUTO)
+    devc.configure(primary_visibility=0, traversal=rb.TRAVERSAL_GUARDED)
     assert t.primary_visibility == 1 and t.sphere_only == 0
     assert_same_frame(fb, ob.render(hostc, cam, threads=8), "config scene, wide view")
 
@@ -504,7 +601,7 @@ def test_alternative_kernels_agree_with_default(rtiow):
         assert t.guarded == 0 and t.flagged_samples == 0
         assert_same_frame(got, want, "exact walk only")
     finally:
-        dev.configure(traversal=rb.TRAVERSAL_AUTO)
+        dev.configure(traversal=rb.TRAVERSAL_GUARDED)
 
 
 def test_context_renders_sharded_frames_through_the_c_abi():
@@ -800,7 +897,7 @@ def test_guarded_walk_steps_aside_or_is_timed_when_it_flags(rtiow):
     handle MEASURES — the next frame is the exact walk's, and whichever cost less per sample stays.  A caller who forces a
     walk gets that walk, no measuring."""
     host = rb.HostScene.rtiow()
-    dev = rb.DeviceScene(host, device=0)
+    dev = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)
     cam = rb.rtiow_camera(240, 135, 8, 50)
     want = ob.render(host, cam, threads=8)
     dev.configure(stack_levels=2)
@@ -817,7 +914,7 @@ def test_guarded_walk_steps_aside_or_is_timed_when_it_flags(rtiow):
     exact = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_EXACT)
     want, _ = exact.render_to_host(cam)
     assert_same_frame(want[100:104], ob.render(host, cam, row0=100, row1=104, threads=8), "exact walk against the oracle")
-    dev = rb.DeviceScene(host, device=0)
+    dev = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)
     fb, t = dev.render_to_host(cam)
     share = t.flagged_samples / (640 * 360 * 16)
     assert t.guarded == 1 and t.abandoned_passes == 0 and t.guard_paused == 0 and 0.004 < share < 0.09, share
@@ -830,7 +927,7 @@ def test_guarded_walk_steps_aside_or_is_timed_when_it_flags(rtiow):
     assert_same_frame(fb, want, "third frame")
     fb, t4 = dev.render_to_host(cam)
     assert t4.guarded == t3.guarded, "no further measuring"
-    forced = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_GUARDED)
+    forced = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_GUARDED, guard_keep=0)
     for k in range(3):
         fb, t = forced.render_to_host(cam)
         assert t.guarded == 1, "a forced walk is not second-guessed by timing"
@@ -869,7 +966,7 @@ def test_heavily_flagged_scene_costs_little_more_than_the_exact_walk():
     assert_same_frame(fb, want, "guarded walk kept, every flagged sample re-walked from the staged list")
     assert tk.kernel_ms < 4.0 * exact_ms, (tk.kernel_ms, exact_ms)          # (was 15 x)
 
-    dev = rb.DeviceScene(host, device=0)                                                 # the defaults
+    dev = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)                                                 # the defaults
     fb, t = dev.render_to_host(cam)
     assert t.guarded == 1 and t.abandoned_passes == 1 and t.guard_paused == 1
     assert_same_frame(fb, want, "abandoned pass")
@@ -879,7 +976,7 @@ def test_heavily_flagged_scene_costs_little_more_than_the_exact_walk():
     assert_same_frame(fb, want, "frame after the abandoned one")
 
     # an asynchronous caller that never asks for timings: the second frame already runs on the exact walk
-    dev = rb.DeviceScene(host, device=0)
+    dev = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)
     f = torch.zeros((720, 1280, 3), dtype=torch.float32, device="cuda:0")
     stream = torch.cuda.Stream()
     t = dev.render(cam, f.data_ptr(), stream=stream.cuda_stream, sync=False)
@@ -890,7 +987,7 @@ def test_heavily_flagged_scene_costs_little_more_than_the_exact_walk():
     stream.synchronize()
     assert_same_frame(f.cpu().numpy(), want, "asynchronous caller")
     # … and one that queues frames without ever waiting: the judgement arrives a few frames late, never wrong
-    dev = rb.DeviceScene(host, device=0)
+    dev = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)
     walks = []
     for k in range(8):
         walks.append(dev.render(cam, f.data_ptr(), stream=stream.cuda_stream, sync=False).guarded)
@@ -938,9 +1035,11 @@ def test_guarded_walk_far_camera_and_ties(force_guarded):
 def force_guarded():
     """rt_config for every handle the test makes or re-configures: guarded walk whatever the scene's size, and kept even
     after a frame that flags more than 2 % of its samples (such a handle would otherwise switch to the exact walk)."""
+    before = dict(rb.DEFAULTS)
     rb.DEFAULTS.update(traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
     yield
     rb.DEFAULTS.clear()
+    rb.DEFAULTS.update(before)
 
 
 def test_guarded_walk_on_plane_scenes(config_scene, force_guarded):

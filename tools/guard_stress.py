@@ -53,8 +53,23 @@ def main():
     seed, count, spp = int(os.environ.get("SEED", "1")), int(os.environ.get("SCENES", "24")), int(os.environ.get("SPP", "48"))
     total_bad = total_samples = over = 0
     worst = 0.0
+    only = os.environ.get("TRIAL")          # one scene of the sequence, with the variants' timing details
     for trial, sph, pl, mats, cam, spread in scenes(seed, count, spp):
+        if only is not None and trial != int(only):
+            continue
         host = rb.HostScene.from_arrays(sph, pl, mats)
+        if only is not None:
+            for what, kw in (("default", {}), ("forced guarded, kept", dict(traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)),
+                             ("forced guarded", dict(traversal=rb.TRAVERSAL_GUARDED)), ("default, no bail-out", dict(guard_bail_share=-1)),
+                             ("exact", dict(traversal=rb.TRAVERSAL_EXACT))):
+                d = rb.DeviceScene(host, 0, **kw)
+                for k in range(3):
+                    _, t = d.render_to_host(cam)
+                    print(f"{what:22s} frame {k}: {t.kernel_ms:7.2f} ms guarded {t.guarded} abandoned {t.abandoned_passes} paused {t.guard_paused} trace {t.trace_ms:6.2f} re-walk {t.rework_ms:6.2f} primary "
+                          f"{t.primary_ms:5.2f} (on {t.primary_visibility}) flagged {t.flagged_samples} lds {t.lds_bytes} in_lds {t.scene_in_lds} wgs {t.num_workgroups} x {t.workgroup_size} "
+                          f"dyn {t.guard_dynamic} simple {t.sphere_only} vgprs {t.trace_vgprs}", flush=True)
+                d.close()
+            continue
         n_samples = W * H * spp
         exact = rb.DeviceScene(host, 0, traversal=rb.TRAVERSAL_EXACT)
         exact.render_to_host(cam)                        # warm-up (code objects, clocks, the slab)
