@@ -515,3 +515,88 @@ void orc_write_color(const float rgb_sum[3], int divisor, uint8_t out[3]) {
         out[k] = (uint8_t)(256 * c);
     }
 }
+
+/* ---- batched views of the primitives above, for tests/test_ref_geom.py --------------------------------------------------------
+ * The same calls, on the same arrays, as oracle/ref_geom.cpp makes on the reference's own headers (compiled from where they lie):
+ * the test compares the two bit for bit.  Nothing here computes anything new. */
+static ray ray_of(const float *o, const float *d) { ray r; memcpy(r.o.e, o, 12); memcpy(r.d.e, d, 12); return r; }
+static void put_rec(float *f, int32_t *code, const hitrec *rec, int id) {
+    f[0] = rec->t; memcpy(f + 1, rec->point.e, 12); memcpy(f + 4, rec->normal.e, 12); f[7] = rec->u; f[8] = rec->v;
+    *code = (rec->front_face ? 1 : 0) | (id << 1);
+}
+void orc_geom_aabb_hit(int64_t n, const float *boxes, const float *origins, const float *dirs, const float *tmin, const float *tmax, int32_t *out) {
+    for (int64_t k = 0; k < n; ++k) { ray r = ray_of(origins + 3 * k, dirs + 3 * k); out[k] = aabb_hit(boxes + 6 * k, &r, tmin[k], tmax[k]); }
+}
+void orc_geom_vec3_div(int64_t n, const float *a, const float *t, float *out) {
+    for (int64_t k = 0; k < n; ++k) { v3 r = divf(V(a[3 * k], a[3 * k + 1], a[3 * k + 2]), t[k]); memcpy(out + 3 * k, r.e, 12); }
+}
+void orc_geom_unit_vector(int64_t n, const float *a, float *out) {
+    for (int64_t k = 0; k < n; ++k) { v3 r = unit(V(a[3 * k], a[3 * k + 1], a[3 * k + 2])); memcpy(out + 3 * k, r.e, 12); }
+}
+void orc_geom_reflect(int64_t n, const float *a, const float *nrm, float *out) {
+    for (int64_t k = 0; k < n; ++k) { v3 r = reflect(V(a[3 * k], a[3 * k + 1], a[3 * k + 2]), V(nrm[3 * k], nrm[3 * k + 1], nrm[3 * k + 2])); memcpy(out + 3 * k, r.e, 12); }
+}
+void orc_geom_refract(int64_t n, const float *a, const float *nrm, const float *eta, float *out) {
+    for (int64_t k = 0; k < n; ++k) {
+        v3 r = refract(V(a[3 * k], a[3 * k + 1], a[3 * k + 2]), V(nrm[3 * k], nrm[3 * k + 1], nrm[3 * k + 2]), eta[k]);
+        memcpy(out + 3 * k, r.e, 12);
+    }
+}
+void orc_geom_near_zero(int64_t n, const float *a, int32_t *out) {
+    for (int64_t k = 0; k < n; ++k) out[k] = near_zero(V(a[3 * k], a[3 * k + 1], a[3 * k + 2]));
+}
+void orc_geom_dot_cross_len(int64_t n, const float *a, const float *b, float *out_dot, float *out_cross, float *out_len) {
+    for (int64_t k = 0; k < n; ++k) {
+        v3 x = V(a[3 * k], a[3 * k + 1], a[3 * k + 2]), y = V(b[3 * k], b[3 * k + 1], b[3 * k + 2]), c = cross(x, y);
+        out_dot[k] = dot(x, y); memcpy(out_cross + 3 * k, c.e, 12); out_len[k] = len(x);
+    }
+}
+void orc_geom_contains(int64_t n, const float *lo, const float *hi, const float *x, int32_t *out) {
+    for (int64_t k = 0; k < n; ++k) out[k] = contains(lo[k], hi[k], x[k]);
+}
+void orc_geom_ray_at(int64_t n, const float *origins, const float *dirs, const float *t, float *out) {
+    for (int64_t k = 0; k < n; ++k) { ray r = ray_of(origins + 3 * k, dirs + 3 * k); v3 p = ray_at(&r, t[k]); memcpy(out + 3 * k, p.e, 12); }
+}
+void orc_geom_set_face_normal(int64_t n, const float *dirs, const float *outward, float *out_normal, int32_t *out_front) {
+    const float zero[3] = {0, 0, 0};
+    for (int64_t k = 0; k < n; ++k) {
+        ray r = ray_of(zero, dirs + 3 * k);
+        hitrec rec;
+        set_face_normal(&rec, &r, V(outward[3 * k], outward[3 * k + 1], outward[3 * k + 2]));
+        memcpy(out_normal + 3 * k, rec.normal.e, 12);
+        out_front[k] = rec.front_face;
+    }
+}
+/* item k: ray k against sphere k / plane k (records in the ABI's layouts); code = front_face | (k & 0xffff) << 1 */
+void orc_geom_hit_sphere(int64_t n, const float *origins, const float *dirs, const float *tmin, const float *tmax, const rt_sphere *spheres,
+                         int32_t *out_hit, float *out_rec9, int32_t *out_code) {
+    for (int64_t k = 0; k < n; ++k) {
+        ray r = ray_of(origins + 3 * k, dirs + 3 * k);
+        hitrec rec;
+        memset(&rec, 0, sizeof(rec));
+        out_hit[k] = hit_sphere(&r, tmin[k], tmax[k], &rec, &spheres[k]);
+        if (out_hit[k]) put_rec(out_rec9 + 9 * k, out_code + k, &rec, (int)(k & 0xffff));
+    }
+}
+void orc_geom_hit_plane(int64_t n, const float *origins, const float *dirs, const float *tmin, const float *tmax, const rt_plane *planes,
+                        int32_t *out_hit, float *out_rec9, int32_t *out_code) {
+    for (int64_t k = 0; k < n; ++k) {
+        ray r = ray_of(origins + 3 * k, dirs + 3 * k);
+        hitrec rec;
+        memset(&rec, 0, sizeof(rec));
+        out_hit[k] = hit_plane(&r, tmin[k], tmax[k], &rec, &planes[k]);
+        if (out_hit[k]) put_rec(out_rec9 + 9 * k, out_code + k, &rec, (int)(k & 0xffff));
+    }
+}
+/* hit_bvh for n rays; code = front_face | (2 * primitive index + type) << 1 */
+void orc_geom_hit_bvh(const rt_scene_desc *scene, int64_t n, const float *origins, const float *dirs, float tmin, float tmax,
+                      int32_t *out_hit, float *out_rec9, int32_t *out_code) {
+    for (int64_t k = 0; k < n; ++k) {
+        ray r = ray_of(origins + 3 * k, dirs + 3 * k);
+        hitrec rec;
+        memset(&rec, 0, sizeof(rec));
+        int pt = -1, pi = -1;
+        out_hit[k] = scene->num_nodes > 0 ? hit_bvh(scene, &r, tmin, tmax, &rec, &pt, &pi, NULL) : 0;
+        if (out_hit[k]) put_rec(out_rec9 + 9 * k, out_code + k, &rec, 2 * pi + pt);
+    }
+}
