@@ -187,6 +187,7 @@ struct rt_scene {
     double guarded_ns_per_sample = 0.0, exact_ns_per_sample = 0.0;
     bool explore_exact = false;
     uint64_t frame_serial = 0;      // render calls so far (a feedback slot knows which one it belongs to)
+    uint32_t trip_test = 0;         // developer build: rt_debug_trip_test
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
@@ -194,8 +195,8 @@ struct rt_scene {
     // accumulation of all other pixels on the caller's stream
     uint32_t *dirty = nullptr, *dirty_list = nullptr;      // per local pixel: mark, list of marked pixels
     size_t dirty_cap = 0;
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux_stream = nullptr, list_stream = nullptr;      // (list_stream: the marked pixels are listed beside the re-walk)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_listed = nullptr;
     uint32_t *cand = nullptr;       // primary visibility: per local pixel rtk::kCandWords words (candidate leaves), grown on demand
     size_t cand_pixels = 0;
     float4 *wf_pool = nullptr;      // render_kernel_wf: ray/hit stacks of every resident wave, grown on demand
@@ -308,6 +309,7 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     if ((uint64_t)P.local_rows * (uint64_t)P.row_w > (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "more than 2^24 pixels per call");
     P.total_work = 0;      // set per pass in rt_render
     P.stats = sc->queue + kQueueStats;
+    P.trip_test = sc->trip_test;
     {
         const uint64_t pixels = (uint64_t)P.local_rows * (uint64_t)P.row_w;
         if (!make_magic((uint32_t)P.row_w, pixels + 1, P.magic_width) ||
@@ -556,6 +558,8 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list); (void)hipFree(sc->wf_pool);
     (void)hipFree(sc->dirty); (void)hipFree(sc->dirty_list); (void)hipFree(sc->cand);
     if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
+    if (sc->list_stream) (void)hipStreamDestroy(sc->list_stream);
+    if (sc->ev_listed) (void)hipEventDestroy(sc->ev_listed);
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
     if (sc->ev_join) (void)hipEventDestroy(sc->ev_join);
     for (hipEvent_t e : sc->pass_events) (void)hipEventDestroy(e);
@@ -816,15 +820,18 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         }
         if (const int forced = cfg.stack_levels) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
         if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
+        // pair walks read through L1 / L2 keep a 1 KB buffer per wave for the sphere records their lanes send for when they park a
+        // leaf (rt_kernel.hip.inc, send_for_leaf)
+        const uint64_t leaf_bytes = (!fast.in_lds && !wide && !want_wavefront && RTP_LEAF_PREFETCH) ? (uint64_t)(gblock / rtk::kWave) * 1024u : 0u;
         if (!fast.in_lds && cfg.lds_treelet) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
-            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);
+            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u) + leaf_bytes + 128u;
             const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;
             const int32_t top_have = wide ? sc->num_top_wide : sc->num_top_pairs;
             fast.num_top = (int32_t)(fit < top_have ? fit : top_have);
         }
         if (!fast.in_lds || fast.wgs_per_cu != gwgs_per_cu) simple = false;      // (cannot happen after the fit test above; the general kernel is always right)
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (!want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (!want_wavefront ? 16u * rtk::kConstRows : 0u) + leaf_bytes) + pool_bytes +
                                     (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
         // what is left of the workgroup's LDS share stages flagged samples per wave (render_kernel, flag_append): 32, 16 or 8 words
@@ -910,6 +917,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         }
         if (cfg.overlap_rework >= 0 && !sc->aux_stream) {
             HIP_TRY(hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&sc->list_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sc->ev_listed, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
         }
@@ -951,9 +960,10 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
                          cfg.flag_capacity == 0 && !gamma_unproven(cfg);
     // an early return between the fork to the second stream and the join must not leave that stream running unobserved
     struct JoinOnExit {
-        rt_scene *sc; hipStream_t stream; bool forked = false;
+        rt_scene *sc; hipStream_t stream; bool forked = false, listing = false;
         ~JoinOnExit() {
             if (forked && hipEventRecord(sc->ev_join, sc->aux_stream) == hipSuccess) (void)hipStreamWaitEvent(stream, sc->ev_join, 0);
+            if (listing) (void)hipStreamWaitEvent(stream, sc->ev_listed, 0);
         }
     } join_guard{sc, stream};
     // Primary visibility without a walk (rt_primary.hip.inc): the pair-node walks of render_kernel — the LDS-resident octant walk
@@ -1205,10 +1215,14 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
                 HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_fork, 0));
                 join_guard.forked = true;
                 launch_stream = sc->aux_stream;
-                // the pixels the trace launch marked, as a list for the second accumulate launch
-                hipLaunchKernelGGL(rtk::dirty_compact_kernel, dim3((num_pixels + rtk::kDirtyBlock - 1) / rtk::kDirtyBlock), dim3(rtk::kDirtyBlock), 0, sc->aux_stream,
+                // the pixels the trace launch marked, as a list for the second accumulate launch — made on a third stream beside the
+                // re-walk (0.2 ms at 1080p that would otherwise lengthen the re-walk's chain past the other pixels' accumulation)
+                HIP_TRY(hipStreamWaitEvent(sc->list_stream, sc->ev_fork, 0));
+                hipLaunchKernelGGL(rtk::dirty_compact_kernel, dim3((num_pixels + rtk::kDirtyBlock - 1) / rtk::kDirtyBlock), dim3(rtk::kDirtyBlock), 0, sc->list_stream,
                                    (const uint32_t *)sc->dirty, num_pixels, sc->dirty_list, sc->queue + kQueueDirty + pass);
                 HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(sc->ev_listed, sc->list_stream));
+                join_guard.listing = true;
             }
             HIP_TRY(launch_exact(R, grid_for(exact)));
             launch_stream = stream;
@@ -1226,6 +1240,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         if (overlapped) {
             // (a pass the guarded launch gave up has rows nobody traced yet: both launches stand down — P.abandon — and a third one,
             // after the re-walk of everything, sums every pixel)
+            HIP_TRY(hipStreamWaitEvent(sc->aux_stream, sc->ev_listed, 0));
+            join_guard.listing = false;
             hipLaunchKernelGGL(rtk::accumulate_kernel<true>, acc_grid, acc_block, 0, sc->aux_stream, d_fb_sum, (const float *)sc->slab, num_pixels, P.slab_pitch,
                                P.pass_count, pass == 0 ? 1 : 0, sc->dirty, (const uint32_t *)sc->dirty_list, (const uint32_t *)(sc->queue + kQueueDirty + pass),
                                (const uint32_t *)nullptr, 0u, 0.0f, 0.0f, 0.0f, (const uint32_t *)P.abandon, 0u);
@@ -1413,6 +1429,15 @@ rt_status rt_debug_check_fast_math(uint64_t out[3]) {
     if (e == hipSuccess) e = hipMemcpy(out, d, 24, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     HIP_TRY(e);
+    return RT_OK;
+}
+
+// Developer hook (not part of the ABI header): the next render calls of this scene inject the fault the tripwire exists for
+// (rt_kernel.hip.inc, RTP_TRIPWIRE) — rt_last_timing must then fail with RT_ERR_HIP and the tripwire's code instead of the
+// launch hanging.  0 switches it off again.
+rt_status rt_debug_trip_test(rt_scene *sc, uint32_t on) {
+    if (!sc) return fail(RT_ERR_INVALID_ARG, "null argument");
+    sc->trip_test = on;
     return RT_OK;
 }
 

@@ -106,7 +106,12 @@ RT_HD uint32_t wang_hash(uint32_t s) {
 }
 RT_HD float random_float(uint32_t &seed) {      // may return exactly 1.0f
     seed = wang_hash(seed);
-    return (float)seed * 2.3283064365386962890625e-10f;   // / 4294967296.0f, exact scaling
+    // / 4294967296.0f: an exact scaling, so ldexp gives the bits of the multiplication (include/random_utils.h:18).  On the
+    // device it also keeps the constant 2^-32 out of the vector registers: as a multiplier the compiler paired it with another
+    // product into one v_pk_mul_f32, and the register pair it pinned for that across the render kernel's main loop was the one
+    // thing the 64-register build had to spill (reloaded in every glass shade step); v_ldexp_f32 takes its exponent from a
+    // scalar register.
+    return __builtin_ldexpf((float)seed, -32);
 }
 // min + (max - min) * r = -1 + 2 * r.  r = (float)seed * 2^-32 and 2 * r are exact (powers of two), so the one rounding of
 // the sum is the one rounding of fma((float)seed, 2^-31, -1): two instructions per coordinate instead of four in the

@@ -97,3 +97,25 @@ def test_sphere_roots_from_one_reciprocal_match_the_plain_divisions():
     assert out[2] == 2 ** 32
     assert out[1] > 2 ** 26          # accepted roots are really being produced and compared
     assert out[0] == 0, "%d operand sets differ" % out[0]
+
+
+def test_tripwire_turns_a_scheduling_fault_into_an_error():
+    """The developer build checks, at every step-kind vote, that each live lane is walking, stuck at a leaf or finished, and counts
+    main-loop rounds without progress (rt_kernel.hip.inc, RTP_TRIPWIRE).  rt_debug_trip_test injects the fault round 3's hang
+    came from — a lane at a leaf with its park slot empty: the launch ENDS, rt_last_timing reports RT_ERR_HIP with the tripwire's
+    code, and the next frame of the same handle is the oracle's again."""
+    lib = rb.amd_lib()
+    lib.rt_debug_trip_test.argtypes = [C.c_void_p, C.c_uint32]
+    host = rb.HostScene.rtiow()
+    dev = rb.DeviceScene(host, device=0, honour_env=False, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
+    cam = rb.rtiow_camera(160, 90, 8, 50)
+    want = ob.render(host, cam, threads=8)
+    fb, t = dev.render_to_host(cam)
+    assert t.guarded == 1
+    assert_same_frame(fb, want, "developer build, tripwire armed, no fault")
+    assert lib.rt_debug_trip_test(dev._h, 1) == 0
+    with pytest.raises(rb.RtError, match="aborted.*1414678785"):          # 0x54524901: kTripPartition
+        dev.render_to_host(cam)
+    assert lib.rt_debug_trip_test(dev._h, 0) == 0
+    fb, t = dev.render_to_host(cam)
+    assert_same_frame(fb, want, "frame after the tripped one")
