@@ -175,6 +175,8 @@ def _fold_pmc(out, args):
             "valu_issue_utilisation": round(issue, 4), "valu_lane_utilisation": round(lanes, 4),
             "valu_wave_instructions_per_launch": valu["SQ_INSTS_VALU"],
             "valu_wave_instructions_per_sample": round(valu["SQ_INSTS_VALU"] / max(roof.get("samples_per_launch", 1), 1), 2),
+            # (sky pixels are nobody's work: the same count over the samples the trace kernel actually took)
+            "valu_wave_instructions_per_traced_sample": round(valu["SQ_INSTS_VALU"] / max(roof.get("traced_samples_per_launch") or roof.get("samples_per_launch", 1), 1), 2),
             "wave_time_split": {"issuing": round(valu["SQ_ACTIVE_INST_ANY"] / valu["SQ_WAVE_CYCLES"], 3),
                                 "s_waitcnt": round(valu["SQ_WAIT_ANY"] / valu["SQ_WAVE_CYCLES"], 3),
                                 "issue_stalled": round(valu["SQ_WAIT_INST_ANY"] / valu["SQ_WAVE_CYCLES"], 3)},
@@ -498,6 +500,8 @@ def worker(args):
                                  if last_t[0] is not None else None),
             "primary_visibility_pass_ms": round(float(np.mean(primary_ms)), 3) if primary_ms else None,
             "samples_per_launch": local_samples // max(n_launch, 1),
+            "traced_samples_per_launch": (int(last_t[0].traced_samples) // max(n_launch, 1)) if last_t[0] is not None else None,
+            "abandoned_passes": int(last_t[0].abandoned_passes) if last_t[0] is not None else None,
             "rework_launch_ms": round(float(np.mean(rework_ms)) / max(n_launch, 1), 3) if rework_ms else None,
             "flagged_sample_fraction": round(float(np.mean(flagged)) / max(local_samples, 1), 6) if flagged else None,
             "step_kernels_ms": round(k_ms, 3),

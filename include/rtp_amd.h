@@ -159,6 +159,8 @@ typedef struct rt_timing {
     uint32_t trace_scratch_bytes; /* … and its scratch (spill) bytes per lane */
     uint32_t abandoned_passes; /* guarded passes that gave up part-way because too many of their samples were being flagged
                                   (rt_config.guard_bail_share): the exact walk rendered those passes whole */
+    uint64_t traced_samples;  /* samples the trace kernel worked on: all of them, or with the primary-visibility pass those of the pixels
+                                  some leaf can be hit through (the others got the background without any per-sample work) */
     uint32_t guard_paused;    /* 1: this handle has stepped aside to the exact walk for its next frames (a frame abandoned a pass or
                                   flagged more than the bail share of its samples; rt_config.guard_keep = 1 prevents it) */
 } rt_timing;

@@ -188,6 +188,8 @@ struct rt_scene {
     bool explore_exact = false;
     uint64_t frame_serial = 0;      // render calls so far (a feedback slot knows which one it belongs to)
     uint32_t trip_test = 0;         // developer build: rt_debug_trip_test
+    const uint32_t *last_traced_pixels = nullptr;     // device word of the last call's primary-visibility pass (null: every pixel was traced)
+    int32_t last_spp = 0;
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
     size_t flag_cap = 0;
@@ -820,18 +822,15 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         }
         if (const int forced = cfg.stack_levels) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
         if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
-        // pair walks read through L1 / L2 keep a 1 KB buffer per wave for the sphere records their lanes send for when they park a
-        // leaf (rt_kernel.hip.inc, send_for_leaf)
-        const uint64_t leaf_bytes = (!fast.in_lds && !wide && !want_wavefront && RTP_LEAF_PREFETCH) ? (uint64_t)(gblock / rtk::kWave) * 1024u : 0u;
         if (!fast.in_lds && cfg.lds_treelet) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
-            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u) + leaf_bytes + 128u;
+            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);
             const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;
             const int32_t top_have = wide ? sc->num_top_wide : sc->num_top_pairs;
             fast.num_top = (int32_t)(fit < top_have ? fit : top_have);
         }
         if (!fast.in_lds || fast.wgs_per_cu != gwgs_per_cu) simple = false;      // (cannot happen after the fit test above; the general kernel is always right)
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (!want_wavefront ? 16u * rtk::kConstRows : 0u) + leaf_bytes) + pool_bytes +
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (!want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
                                     (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
         // what is left of the workgroup's LDS share stages flagged samples per wave (render_kernel, flag_append): 32, 16 or 8 words
@@ -1300,6 +1299,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     sc->last.trace_scratch_bytes = trace_scratch;
     sc->last_passes = passes;
     sc->last_samples = (uint64_t)num_pixels * (uint64_t)P.spp;
+    sc->last_traced_pixels = prim ? P.traced_pixels : nullptr;
+    sc->last_spp = P.spp;
     if (sync) return rt_last_timing(sc, timing);
     timing_out(sc->last, timing);
     return RT_OK;
@@ -1350,6 +1351,12 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
         // back — dense overlaps, a camera inside a sphere, … — is cheaper on the exact walk alone; later frames of this handle use it)
         if (const rt_status ps = poll_feedback(sc, true)) return ps;
         sc->last.guard_paused = sc->guard_paused ? 1u : 0u;
+        sc->last.traced_samples = sc->last_samples;
+        if (sc->last_traced_pixels) {
+            uint32_t traced = 0;
+            HIP_TRY(hipMemcpy(&traced, sc->last_traced_pixels, 4, hipMemcpyDeviceToHost));
+            sc->last.traced_samples = (uint64_t)traced * (uint64_t)sc->last_spp;
+        }
         uint32_t abort_code = 0;
         HIP_TRY(hipMemcpy(&abort_code, sc->queue + kQueueStats + 15, 4, hipMemcpyDeviceToHost));
         if (abort_code != 0) return fail(RT_ERR_HIP, "render kernel aborted (protocol timeout, code " + std::to_string(abort_code) + ")");

@@ -66,7 +66,7 @@ class Timing(C.Structure):
                 ("guard_unproven", C.c_uint32), ("kernel", C.c_uint32), ("guard_dynamic", C.c_uint32), ("wide_nodes", C.c_uint32),
                 ("sphere_only", C.c_uint32), ("primary_visibility", C.c_uint32), ("primary_ms", C.c_float),
                 ("trace_vgprs", C.c_uint32), ("trace_scratch_bytes", C.c_uint32), ("abandoned_passes", C.c_uint32),
-                ("guard_paused", C.c_uint32)]
+                ("traced_samples", C.c_uint64), ("guard_paused", C.c_uint32)]
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
