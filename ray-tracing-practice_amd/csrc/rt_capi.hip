@@ -1217,7 +1217,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
                 // the pixels the trace launch marked, as a list for the second accumulate launch — made on a third stream beside the
                 // re-walk (0.2 ms at 1080p that would otherwise lengthen the re-walk's chain past the other pixels' accumulation)
                 HIP_TRY(hipStreamWaitEvent(sc->list_stream, sc->ev_fork, 0));
-                hipLaunchKernelGGL(rtk::dirty_compact_kernel, dim3((num_pixels + rtk::kDirtyBlock - 1) / rtk::kDirtyBlock), dim3(rtk::kDirtyBlock), 0, sc->list_stream,
+                hipLaunchKernelGGL(rtk::dirty_compact_kernel, dim3((num_pixels + rtk::kDirtyPixels - 1) / rtk::kDirtyPixels), dim3(rtk::kDirtyBlock), 0, sc->list_stream,
                                    (const uint32_t *)sc->dirty, num_pixels, sc->dirty_list, sc->queue + kQueueDirty + pass);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(sc->ev_listed, sc->list_stream));

@@ -20,6 +20,7 @@ print('C5 %d spp: kernel_ms %.1f trace_ms %.1f primary %.1f rework %.1f launches
 if os.environ.get('STATS'):
     lib=rb.amd_lib(); out=(C.c_uint32*16)(); lib.rt_debug_read_stats(ds._h, out)
     print('  shade block split (kticks): (A) store+fetch %d   (C)+(B) material+arm %d   rest %d   votes %d' % (out[12], out[13], out[10], out[11]))
+    print('  why flagged (RTP_STATS without the shade split): full stack %d, exact tie %d, final check / Schlick window %d' % (out[12], out[13], out[14]))
     names=['pair','leaf','shadephase','shade']
     for k,n in enumerate(names):
         it,ln=out[2*k],out[2*k+1]
