@@ -742,8 +742,11 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
 #ifndef RTP_DEV_BUILD
     if (want_wavefront) return fail(RT_ERR_UNSUPPORTED, "RT_KERNEL_WAVEFRONT is an experiment of the developer build (make dev): not in this library");
 #endif
-    // 4-wide nodes where the scene has them (host-built tree with at least one inner node) and the configuration does not
-    // ask for the pair nodes; the wavefront kernel walks pairs
+    // 4-wide nodes (developer build only: measured 6 % slower on S-rtiow and 34 % slower on S-100k than the pair walks as they are
+    // now — docs/LOG.md) where the scene has them (host-built tree with at least one inner node); the wavefront kernel walks pairs
+#ifndef RTP_DEV_BUILD
+    if (cfg.wide_nodes != 0) return fail(RT_ERR_UNSUPPORTED, "rt_config.wide_nodes is an experiment of the developer build (make dev): not in this library");
+#endif
     const bool wide = sc->wnodes != nullptr && sc->num_wide > 0 && cfg.wide_nodes != 0 && !want_wavefront;
     uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
     int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
@@ -1172,11 +1175,13 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
                 (void)launch_wf;
 #endif
             } else if (wide) {
+#ifdef RTP_DEV_BUILD
                 if (dyn) {
                     if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true, true>, P, wgs, fast.lds_bytes));
                     else HIP_TRY(launch(rtk::render_kernel<false, false, true, true>, P, wgs, fast.lds_bytes));
                 } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, false, true>, P, wgs, fast.lds_bytes));
+#endif
             } else if (dyn && prim) {
                 if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true, false, false, true>, P, wgs, fast.lds_bytes));

@@ -730,39 +730,6 @@ def test_distance_aware_margins_with_the_by_pixel_primary_pass():
     assert_same_frame(fb, ob.render(host, cam, row0=1300, row1=1302, threads=16), "S-100k, rows 1300-1301 at 130 spp")
 
 
-def test_wide_nodes_give_the_same_frames(config_scene):
-    """rt_config.wide_nodes = 1: the guarded walk on the 4-wide collapse of its tree (step_wide; SURVEY.md §8(f3) "wide
-    nodes") — LDS-resident tables (S-rtiow, the config scene with its planes), tables read through L1/L2 with a treelet
-    in LDS (6 500 spheres), with distance-aware margins and a 3-entry stack (overflow flags): the oracle's frames."""
-    host = rb.HostScene.rtiow()
-    cam = rb.rtiow_camera(240, 135, 8, 50)
-    want = ob.render(host, cam, threads=8)
-    dev = rb.DeviceScene(host, device=0, honour_env=False, wide_nodes=1)
-    fb, t = dev.render_to_host(cam)
-    assert t.guarded == 1 and t.wide_nodes == 1 and t.scene_in_lds == 1
-    assert_same_frame(fb, want, "S-rtiow, wide nodes")
-    dev.configure(stack_levels=3, guard_keep=1)
-    fb, t3 = dev.render_to_host(cam)
-    assert t3.wide_nodes == 1 and t3.flagged_samples > t.flagged_samples
-    assert_same_frame(fb, want, "S-rtiow, wide nodes, 3-entry stack")
-    dev = rb.DeviceScene(host, device=0, honour_env=False, wide_nodes=1, guard_dynamic_margins=2)
-    fb, t = dev.render_to_host(cam)
-    assert t.wide_nodes == 1 and t.guard_dynamic == 1
-    assert_same_frame(fb, want, "S-rtiow, wide nodes + distance-aware margins")
-    chost, _ = config_scene
-    dev = rb.DeviceScene(chost, device=0, honour_env=False, wide_nodes=1, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
-    ccam = chost.frame_camera(0)
-    fb, t = dev.render_to_host(ccam)
-    assert t.guarded == 1 and t.wide_nodes == 1
-    assert_same_frame(fb, ob.render(chost, ccam, threads=8), "config scene, wide nodes")
-    big = rb.HostScene.rtiow(half_extent=40)
-    dev = rb.DeviceScene(big, device=0, honour_env=False, wide_nodes=1)
-    bcam = rb.rtiow_camera(320, 180, 4, 50)
-    fb, t = dev.render_to_host(bcam)
-    assert t.guarded == 1 and t.wide_nodes == 1 and t.scene_in_lds == 0
-    assert_same_frame(fb, ob.render(big, bcam, threads=8), "6 500 spheres through L1/L2, wide nodes")
-
-
 def test_config_api_without_environment():
     """A handle created with honour_env=False takes everything from rt_config: forced pass size, a capped stack,
     an opt-in unproven margin (reported in rt_timing.guard_unproven) — frames are the oracle's in every case."""
@@ -1297,6 +1264,8 @@ def test_developer_build_checks():
     host = rb.HostScene.rtiow()
     with pytest.raises(RuntimeError, match="developer build"):
         rb.DeviceScene(host, device=0, honour_env=False, kernel=rb.KERNEL_WAVEFRONT).render_to_host(rb.rtiow_camera(32, 20, 2, 8))
+    with pytest.raises(RuntimeError, match="developer build"):
+        rb.DeviceScene(host, device=0, honour_env=False, wide_nodes=1).render_to_host(rb.rtiow_camera(32, 20, 2, 8))
     dev_lib = os.path.join(os.path.dirname(HERE), "ray-tracing-practice_amd", "librtp_amd_dev.so")
     assert os.path.exists(dev_lib), "run __graft_entry__.build() (make -C ray-tracing-practice_amd dev)"
     env = dict(os.environ, RTP_AMD_LIB=dev_lib)
