@@ -54,6 +54,7 @@ def main():
     total_bad = total_samples = over = 0
     worst = 0.0
     only = os.environ.get("TRIAL")          # one scene of the sequence, with the variants' timing details
+    extra = eval(os.environ.get("EXTRA", "{}"))
     for trial, sph, pl, mats, cam, spread in scenes(seed, count, spp):
         if only is not None and trial != int(only):
             continue
@@ -75,10 +76,10 @@ def main():
         exact.render_to_host(cam)                        # warm-up (code objects, clocks, the slab)
         e, te = exact.render_to_host(cam)
         exact.close()
-        dev = rb.DeviceScene(host, 0)                    # the defaults
+        dev = rb.DeviceScene(host, 0, **extra)           # the defaults (EXTRA="dict(...)": rt_config fields to try on top of them)
         frames = [dev.render_to_host(cam) for _ in range(3)]
         dev.close()
-        forced = rb.DeviceScene(host, 0, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)
+        forced = rb.DeviceScene(host, 0, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1, **extra)
         g, tg = forced.render_to_host(cam)
         reason = forced.guard_reason() or "eligible"
         forced.close()
