@@ -163,6 +163,8 @@ typedef struct rt_timing {
                                   some leaf can be hit through (the others got the background without any per-sample work) */
     uint32_t guard_paused;    /* 1: this handle has stepped aside to the exact walk for its next frames (a frame abandoned a pass or
                                   flagged more than the bail share of its samples; rt_config.guard_keep = 1 prevents it) */
+    uint32_t front_primitives; /* primitives the guarded walk tested at the start of every ray instead of keeping them in its tree
+                                  (rt_config.guard_front_primitives); 0 when the exact walk ran */
 } rt_timing;
 /* *t = zeros with struct_bytes = sizeof(rt_timing). */
 void rt_timing_init(rt_timing *t);
@@ -237,6 +239,11 @@ typedef struct rt_config {
                                      pass, or flagged more than this share overall, makes the handle use the exact walk from then on —
                                      found at the next render call from what the previous one left in host memory, no rt_last_timing
                                      needed.  Below it RT_TRAVERSAL_AUTO decides by measurement (see traversal) */
+    int32_t  guard_front_primitives; /* (fixed at create) 0 (default): up to four primitives that span the scene — a leaf box of at least half
+                                     the surface of everything that is left: a ground sphere, a floor quad — are not leaves of the guarded
+                                     walk's tree; every ray tests them when it is armed, all lanes of a wave together, and walks with their
+                                     hit as its closest so far (the same frame bit for bit: the guarded walk's result does not depend on
+                                     the order of its tests); -1: every primitive is a leaf of the tree */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */
@@ -249,8 +256,13 @@ rt_status rt_set_device(int32_t device_ordinal);
  * to the device layout and uploads them once. */
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene);
 
-/* Defaults into *cfg (struct_bytes = sizeof(rt_config)). */
+/* Defaults into *cfg.  rt_config grows with the library, like rt_timing: the macro hands over the size the CALLER was compiled
+ * with and the library writes at most that many bytes (struct_bytes = that size) — a caller built against an older, shorter
+ * header keeps working.  A binding that calls the exported function rt_config_init itself (ctypes, cgo: no macro) gets the
+ * library's own sizeof(rt_config) and has to mirror the struct of the library it loads. */
+void rt_config_init_sized(rt_config *cfg, uint32_t struct_bytes);
 void rt_config_init(rt_config *cfg);
+#define rt_config_init(cfg) rt_config_init_sized((cfg), (uint32_t)sizeof(rt_config))
 /* Developer convenience for test harnesses and tools: overlays the RTP_* environment variables (RTP_TRAVERSAL,
  * RTP_BUILD, RTP_SLAB_GIB, RTP_PASS_SPP, …; list in INTEGRATION.md) onto *cfg.  The library itself never reads
  * the environment: a host that wants this behaviour calls it explicitly. */
@@ -259,6 +271,7 @@ void rt_config_from_env(rt_config *cfg);
 rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *cfg, rt_scene **out_scene);
 /* Replace the render-time fields of the scene's configuration (the create-time fields are ignored). */
 rt_status rt_scene_set_config(rt_scene *scene, const rt_config *cfg);
+/* The scene's configuration into *cfg: at most cfg->struct_bytes bytes (set by rt_config_init; below 8: RT_ERR_INVALID_ARG). */
 rt_status rt_scene_get_config(const rt_scene *scene, rt_config *cfg);
 
 /* Replaces destroy_scene_arrays / destroy_texture_resources (src/main.cu:235-246,322-344). */

@@ -576,6 +576,23 @@ void Packer::prepare_guard() {
             }
             if (derivable && !opt.leaf_table) out.leaf_boxes.clear();
             g.ok = why.empty();
+            // ---- front primitives (rt_accel.h): while the largest leaf box spans at least half of the surface of what is left,
+            // it leaves the tree (which keeps at least two leaves: its root stays an inner node)
+            g.num_front = 0;
+            const int front_max = std::min(opt.front_max, kMaxFront);
+            while (g.ok && g.num_front < front_max && leaves.size() > 2) {
+                float all[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+                size_t big = 0;
+                for (size_t k = 0; k < leaves.size(); ++k) {
+                    box_union(all, leaves[k].box, all);
+                    if (half_area(leaves[k].box) > half_area(leaves[big].box)) big = k;
+                }
+                if (!(half_area(leaves[big].box) >= 0.5f * half_area(all))) break;
+                g.front_code[g.num_front] = -(leaves[big].code + 1);
+                std::memcpy(g.front_box[g.num_front], leaves[big].box, sizeof(float) * 6);
+                g.num_front++;
+                leaves.erase(leaves.begin() + static_cast<std::ptrdiff_t>(big));
+            }
         }
         g.reason = why;
     }

@@ -23,6 +23,8 @@ constexpr int32_t kTraversalDone = INT32_MIN;   // "no more nodes" sentinel of t
 
 inline int32_t leaf_code(int32_t prim_index, int32_t prim_type) { return -(2 * prim_index + prim_type) - 1; }
 
+constexpr int kMaxFront = 4;         // front primitives of the guarded walk (Packed::Guard)
+
 struct Packed {
     std::vector<float> nodes;      // 16 floats per internal node
     std::vector<float> hnodes;     // Guarded: the same nodes in 8 floats — boxes as binary16 rounded outward + 2 codes
@@ -74,6 +76,15 @@ struct Packed {
         // 25 %): the camera position is checked against it per render
         float origin_center[3] = {0, 0, 0};
         float origin_radius = 0;
+        // Front primitives (PackOptions::front_max): primitives whose inflated leaf box spans at least half of the surface of
+        // everything that is left (the ground sphere of S-rtiow, a floor quad under a field of spheres) are NOT leaves of
+        // the walk's tree.  Nearly every ray would reach them anyway — through a root step that prunes nothing and a
+        // primitive test in a divergent leaf step; the kernel tests them when it arms a ray instead, all lanes of the
+        // wave together, and the walk starts with their hit as its `closest`.  Codes are 2 * index + type; boxes are the inflated
+        // leaf boxes (x.min x.max y.min y.max z.min z.max), which the per-pixel candidate lists still need (rt_beam.h).
+        int32_t num_front = 0;
+        int32_t front_code[kMaxFront] = {0, 0, 0, 0};
+        float front_box[kMaxFront][6] = {};
     } guard;
     std::vector<float> leaf_boxes;        // 8 floats per sphere: the caller's exact leaf box (+2 pad), for the final check
                                           // (empty when every box is exactly fl(c -/+ r): the kernel recomputes it)
@@ -98,6 +109,7 @@ struct PackOptions {
     bool leaf_table = false;           // always emit the exact sphere leaf boxes as a table (developer)
     int dynamic = 0;                   // distance-aware margins for the small spheres: 0 = where static ones would exceed a
                                        // quarter of the smallest radius, 1 = never, 2 = always
+    int front_max = kMaxFront;         // at most this many front primitives (Packed::Guard::num_front); 0: every primitive is a leaf of the tree
 };
 
 // binary16 helpers of the half-precision node table (exposed for the native test)

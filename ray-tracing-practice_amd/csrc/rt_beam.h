@@ -177,4 +177,19 @@ RT_BEAM_HD int beam_candidates(const Beam &b, NodeTab nodes, int32_t root, doubl
     return n;
 }
 
+// The front primitives of the guarded walk (rt_accel.h, Packed::Guard: scene-spanning primitives that are not leaves of the
+// tree) join a pixel's list by the same two tests a leaf passes in the descent above.  codes: 2 index + type; boxes: 6 floats
+// each, x.min x.max y.min y.max z.min z.max (the inflated leaf boxes).  n: candidates already in out (-1 stays -1).
+RT_BEAM_HD int beam_front_candidates(const Beam &b, int num_front, const int32_t *codes, const float *boxes, double grow_k, uint32_t *out, int n, int max_out) {
+    for (int f = 0; f < num_front && n >= 0; ++f) {
+        const float *x = boxes + 6 * f;
+        const float lo[3] = {x[0], x[2], x[4]}, hi[3] = {x[1], x[3], x[5]};
+        if (!beam_hits_box(b, lo, hi, grow_k)) continue;
+        if (!(codes[f] & 1) && !beam_hits_ball(b, lo, hi, grow_k)) continue;
+        if (n >= max_out) return -1;
+        out[n++] = (uint32_t)codes[f];
+    }
+    return n;
+}
+
 }  // namespace rtbeam

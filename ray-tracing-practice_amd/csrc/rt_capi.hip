@@ -106,6 +106,7 @@ void config_defaults(rt_config &c) {
     c.reserve_taper = 1;
     c.wide_nodes = 0;
     c.guard_bail_share = 0;
+    c.guard_front_primitives = 0;
 }
 
 // A caller compiled against an older, shorter rt_config: its fields, defaults for the rest.
@@ -126,6 +127,8 @@ rtaccel::PackOptions pack_options(const rt_config &cfg) {
     o.dynamic = cfg.guard_dynamic_margins;
     if (cfg.guard_gamma_ulps > 0.0f) o.gamma = (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8;
     o.leaf_table = cfg.guard_exact_leaf_table != 0;
+    // (the developer build's experimental kernels — wavefront, queue, 4-wide nodes — arm their rays themselves: everything stays in the tree)
+    o.front_max = (cfg.guard_front_primitives < 0 || cfg.kernel == RT_KERNEL_WAVEFRONT || cfg.wide_nodes != 0) ? 0 : rtaccel::kMaxFront;
     return o;
 }
 uint32_t bail_share_of(const rt_config &cfg) {      // in 1/256ths; 0 = never
@@ -326,6 +329,9 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.g_rs = sc->guard.cluster_radius;
     P.g_fark = sc->guard.far_k;
     P.g_dynk = sc->guard.dyn_k;
+    P.num_front = sc->guard.num_front;
+    std::memcpy(P.front_code, sc->guard.front_code, sizeof(P.front_code));
+    std::memcpy(P.front_box, sc->guard.front_box, sizeof(P.front_box));
     std::memcpy(P.g_box, sc->guard.box, 24);
     P.k_inner = sc->cfg.k_inner > 0 ? sc->cfg.k_inner : 24;
     P.k_shade = sc->cfg.k_shade > 0 ? sc->cfg.k_shade : 48;
@@ -408,12 +414,24 @@ rt_status rt_set_device(int32_t device_ordinal) {
     return RT_OK;
 }
 
-void rt_config_init(rt_config *cfg) {
+// (the header's macro of the same name calls rt_config_init_sized with the caller's sizeof; this is the symbol FFI bindings reach)
+void (rt_config_init)(rt_config *cfg) {
     if (cfg) config_defaults(*cfg);
 }
+void rt_config_init_sized(rt_config *cfg, uint32_t struct_bytes) {
+    if (!cfg || struct_bytes < 8) return;
+    rt_config c;
+    config_defaults(c);
+    const uint32_t n = struct_bytes < sizeof(rt_config) ? struct_bytes : (uint32_t)sizeof(rt_config);
+    std::memcpy(cfg, &c, n);
+    cfg->struct_bytes = n;
+}
 
-void rt_config_from_env(rt_config *cfg) {
-    if (!cfg) return;
+void rt_config_from_env(rt_config *user) {
+    if (!user || user->struct_bytes < 8) return;
+    // (on a copy of the library's size: a caller compiled against a shorter rt_config gets back only the fields it has)
+    rt_config full = config_from_caller(user);
+    rt_config *cfg = &full;
     auto str_is = [](const char *name, const char *value) { const char *v = getenv(name); return v && std::string(v) == value; };
     if (str_is("RTP_TRAVERSAL", "threaded") || str_is("RTP_TRAVERSAL", "exact")) cfg->traversal = RT_TRAVERSAL_EXACT;
     if (str_is("RTP_TRAVERSAL", "guarded")) cfg->traversal = RT_TRAVERSAL_GUARDED;
@@ -444,6 +462,10 @@ void rt_config_from_env(rt_config *cfg) {
     if (env_int("RTP_NO_OVERLAP", 0)) cfg->overlap_rework = -1;
     if (env_int("RTP_NO_PRIMARY", 0)) cfg->primary_visibility = -1;
     cfg->guard_bail_share = env_int("RTP_BAIL_SHARE", cfg->guard_bail_share);
+    if (env_int("RTP_NO_FRONT", 0)) cfg->guard_front_primitives = -1;
+    const uint32_t n = user->struct_bytes < sizeof(rt_config) ? user->struct_bytes : (uint32_t)sizeof(rt_config);
+    std::memcpy(user, &full, n);
+    user->struct_bytes = n;
 }
 
 rt_status rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) { return rt_scene_create_ex(desc, nullptr, out_scene); }
@@ -456,13 +478,17 @@ rt_status rt_scene_set_config(rt_scene *sc, const rt_config *cfg) {
     c.guard_gamma_ulps = sc->cfg.guard_gamma_ulps;
     c.guard_exact_leaf_table = sc->cfg.guard_exact_leaf_table;
     c.guard_dynamic_margins = sc->cfg.guard_dynamic_margins;
+    c.guard_front_primitives = sc->cfg.guard_front_primitives;
     sc->cfg = c;
     return RT_OK;
 }
 
 rt_status rt_scene_get_config(const rt_scene *sc, rt_config *cfg) {
     if (!sc || !cfg) return fail(RT_ERR_INVALID_ARG, "null argument");
-    *cfg = sc->cfg;
+    if (cfg->struct_bytes < 8) return fail(RT_ERR_INVALID_ARG, "rt_config.struct_bytes is not set (rt_config_init)");
+    const uint32_t n = cfg->struct_bytes < sizeof(rt_config) ? cfg->struct_bytes : (uint32_t)sizeof(rt_config);
+    std::memcpy(cfg, &sc->cfg, n);
+    cfg->struct_bytes = n;
     return RT_OK;
 }
 
@@ -763,6 +789,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
 #ifndef RTP_DEV_BUILD
     if (cfg.wide_nodes != 0) return fail(RT_ERR_UNSUPPORTED, "rt_config.wide_nodes is an experiment of the developer build (make dev): not in this library");
 #endif
+    // (those two arm their rays themselves: a tree without its front primitives — rt_accel.h — is not theirs to walk)
+    if ((want_wavefront || cfg.wide_nodes != 0) && sc->guard.num_front > 0)
+        return fail(RT_ERR_UNSUPPORTED, "the wavefront kernel and 4-wide nodes need a scene handle created with them selected (its tree must hold every primitive)");
     const bool wide = sc->wnodes != nullptr && sc->num_wide > 0 && cfg.wide_nodes != 0 && !want_wavefront;
     uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
     int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
@@ -1326,6 +1355,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     sc->last.guard_unproven = (guarded && gamma_unproven(cfg)) ? 1u : 0u;
     sc->last.kernel = wavefront ? RT_KERNEL_WAVEFRONT : RT_KERNEL_MEGA;
     sc->last.guard_dynamic = dyn ? 1u : 0u;
+    sc->last.front_primitives = guarded ? (uint32_t)sc->guard.num_front : 0u;
     sc->last.wide_nodes = (guarded && wide) ? 1u : 0u;
     sc->last.sphere_only = ((guarded && simple && !wavefront && !wide && !dyn) || (!guarded && exact_simple)) ? 1u : 0u;
     sc->last.primary_visibility = prim ? 1u : 0u;

@@ -66,7 +66,7 @@ class Timing(C.Structure):
                 ("guard_unproven", C.c_uint32), ("kernel", C.c_uint32), ("guard_dynamic", C.c_uint32), ("wide_nodes", C.c_uint32),
                 ("sphere_only", C.c_uint32), ("primary_visibility", C.c_uint32), ("primary_ms", C.c_float),
                 ("trace_vgprs", C.c_uint32), ("trace_scratch_bytes", C.c_uint32), ("abandoned_passes", C.c_uint32),
-                ("traced_samples", C.c_uint64), ("guard_paused", C.c_uint32)]
+                ("traced_samples", C.c_uint64), ("guard_paused", C.c_uint32), ("front_primitives", C.c_uint32)]
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
@@ -88,7 +88,20 @@ class Config(C.Structure):
                 ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
                 ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32),
                 ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32), ("primary_visibility", C.c_int32),
-                ("guard_bail_share", C.c_int32)]
+                ("guard_bail_share", C.c_int32), ("guard_front_primitives", C.c_int32)]
+
+
+def new_config():
+    """rt_config with the library's defaults (what the header's rt_config_init macro does: the CALLER's struct size travels along)."""
+    cfg = Config()
+    lib = amd_lib()
+    if hasattr(lib, "rt_config_init_sized"):
+        lib.rt_config_init_sized(C.byref(cfg), C.sizeof(Config))
+        assert cfg.struct_bytes == C.sizeof(Config), (cfg.struct_bytes, C.sizeof(Config))
+    else:       # an OLDER build loaded through RTP_AMD_LIB for an A/B run (developer tools): it fills the fields it has
+        assert os.environ.get("RTP_AMD_LIB")
+        lib.rt_config_init(C.byref(cfg))
+    return cfg
 
 
 class ConfigInfo(C.Structure):
@@ -101,7 +114,7 @@ assert C.sizeof(BvhNode) == 36 and C.sizeof(CameraData) == 76
 
 # Every symbol include/rtp_amd.h declares (tests check that the library exports all of them).
 RTP_AMD_SYMBOLS = [
-    "rt_set_device", "rt_scene_create", "rt_scene_create_ex", "rt_config_init", "rt_config_from_env", "rt_scene_set_config",
+    "rt_set_device", "rt_scene_create", "rt_scene_create_ex", "rt_config_init", "rt_config_init_sized", "rt_config_from_env", "rt_scene_set_config",
     "rt_scene_get_config", "rt_scene_destroy", "rt_scene_guard_reason", "rt_shard_rows", "rt_render", "rt_render_tile", "rt_last_kernel_ms",
     "rt_last_timing", "rt_timing_init",
     "rt_render_to_host", "rt_trace_samples", "rt_closest_hits", "rt_device_alloc", "rt_device_free", "rt_copy_to_host", "rt_tonemap",
@@ -156,6 +169,9 @@ def amd_lib():
         lib.rt_scene_destroy.argtypes = [C.c_void_p]
         lib.rt_config_init.argtypes = [C.POINTER(Config)]
         lib.rt_config_init.restype = None
+        if hasattr(lib, "rt_config_init_sized"):
+            lib.rt_config_init_sized.argtypes = [C.POINTER(Config), C.c_uint32]
+            lib.rt_config_init_sized.restype = None
         lib.rt_config_from_env.argtypes = [C.POINTER(Config)]
         lib.rt_config_from_env.restype = None
         lib.rt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -310,9 +326,7 @@ class DeviceScene:
         self._keep = host_scene
 
     def _make_config(self):
-        cfg = Config()
-        amd_lib().rt_config_init(C.byref(cfg))
-        assert cfg.struct_bytes == C.sizeof(Config), (cfg.struct_bytes, C.sizeof(Config))
+        cfg = new_config()
         for k, v in {**DEFAULTS, **self._explicit}.items():
             setattr(cfg, k, v)
         if self._honour_env:
@@ -330,6 +344,7 @@ class DeviceScene:
 
     def config(self):
         cfg = Config()
+        cfg.struct_bytes = C.sizeof(Config)
         _check(amd_lib().rt_scene_get_config(self._h, C.byref(cfg)), "rt_scene_get_config")
         return cfg
 
@@ -442,8 +457,7 @@ class Context:
         return amd_lib().rt_context_transport(self._h).decode()
 
     def scene(self, host_scene, **config):
-        cfg = Config()
-        amd_lib().rt_config_init(C.byref(cfg))
+        cfg = new_config()
         for k, v in config.items():
             setattr(cfg, k, v)
         _check(amd_lib().rt_context_scene_create(self._h, C.byref(host_scene.desc), C.byref(cfg)), "rt_context_scene_create")

@@ -178,7 +178,18 @@ int main() {
                 }
                 ++leaves_seen;
             }
-        CHECK(leaves_seen == hs.spheres.size());
+        // the ground sphere spans the scene: a FRONT primitive (tested as a ray is armed), not a leaf — with its inflated box kept
+        CHECK(pk.guard.num_front == 1 && pk.guard.front_code[0] == 0 && hs.spheres[0].radius == 1000.0f);
+        for (int a = 0; a < 3; ++a)
+            CHECK(pk.guard.front_box[0][2 * a] <= hs.spheres[0].center.e[a] - 1000.0 - 1e-4 && pk.guard.front_box[0][2 * a + 1] >= hs.spheres[0].center.e[a] + 1000.0 + 1e-4);
+        CHECK(leaves_seen + 1 == hs.spheres.size());
+        {   // … unless the caller says otherwise
+            rtaccel::PackOptions all_leaves;
+            all_leaves.front_max = 0;
+            rtaccel::Packed pk0;
+            CHECK(rtaccel::pack_scene(hs.desc(), rtaccel::TreeMode::Guarded, pk0, all_leaves).empty());
+            CHECK(pk0.guard.ok && pk0.guard.num_front == 0 && pk0.num_internal == pk.num_internal + 1);
+        }
         // the table the kernel reads: the same boxes as binary16, each plane rounded outward, same child codes
         CHECK(pk.hnodes.size() == (size_t)pk.num_internal * 8);
         for (int32_t k = 0; k < pk.num_internal; ++k) {
@@ -209,6 +220,8 @@ int main() {
         rtp::build_rtiow_scene(o, with_plane);
         CHECK(rtaccel::pack_scene(with_plane.desc(), rtaccel::TreeMode::Guarded, pk).empty());
         CHECK(pk.guard.ok && pk.plane_leaf_boxes.size() == with_plane.planes.size() * 8 && pk.num_tnodes > 0);
+        // the ground sphere, then the floor quad under the field of small spheres (half of what is left once the ground is out)
+        CHECK(pk.guard.num_front == 2 && pk.guard.front_code[0] == 0 && pk.guard.front_code[1] == 1);
         {
             std::vector<rt_plane> planes(with_plane.planes);
             rt_scene_desc dp = with_plane.desc();

@@ -56,7 +56,9 @@ static void check_frame(rtp::HostScene &hs, const rt_camera_data &cam, int step,
     for (int j = 0; j < cam.image_height; j += step)
         for (int i = (j / step) % step; i < cam.image_width; i += step) {
             const rtbeam::Beam b = rtbeam::make_beam(cam.origin.e, cam.pixel00_loc.e, cam.pixel_delta_u.e, cam.pixel_delta_v.e, i, j, cmax);
-            const int n = rtbeam::beam_candidates(b, nodes, pk.root, (double)pk.guard.dyn_k, cand.data(), max_out);
+            int n = rtbeam::beam_candidates(b, nodes, pk.root, (double)pk.guard.dyn_k, cand.data(), max_out);
+            // (+ the front primitives, which are not leaves of that tree: exactly what cand_kernel does)
+            n = rtbeam::beam_front_candidates(b, pk.guard.num_front, pk.guard.front_code, &pk.guard.front_box[0][0], (double)pk.guard.dyn_k, cand.data(), n, max_out);
             st.pixels++;
             if (n < 0) { st.overflow++; continue; }
             st.cand_sum += n;

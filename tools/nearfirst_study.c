@@ -37,6 +37,7 @@ struct snode_s; static void *g_s_any; static void sah_ray(const ray *r, float c_
 static void *g_w_any; static void wide_ray(const ray *r, float c_ref, int prim_ref);
 static int g_defer_on; static void defer_ray(const ray *r, float c_ref, int prim_ref);
 static int g_leafk_on; static void leafk_ray(const ray *r, float c_ref, int prim_ref);
+static int g_model_on; static void model_ray(const ray *r, float c_ref, int prim_ref);
 static int g_fused = 0;
 static inline int aabb_hit_fused(const float box[6], const ray *r, float tmin0, float tmax0, float *enter) {
     float nr[3], fr[3];
@@ -109,6 +110,7 @@ static void study_ray(const void *scv, const void *rv) {
     if (g_w_any) wide_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     if (g_defer_on) defer_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     if (g_leafk_on) leafk_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
+    if (g_model_on) model_ray(r, c_ref, p_ref >= 0 ? nodes[p_ref].right : -1);
     const int flagged = flagged_prune | flagged_incons;
     n_flag += flagged; n_flag_prune += flagged_prune; n_flag_incons += flagged_incons;
     const int mismatch = (p != p_ref) || (p >= 0 && c != c_ref);
@@ -373,6 +375,123 @@ static void leafk_ray(const ray *r, float c_ref, int prim_ref) {
     }
     if ((p != prim_ref) || (p >= 0 && c != c_ref)) k_mismatch++;
 }
+
+/* ---- MODEL=1: the kernel's pair-step walk (round 4 study): what would tighter boxes and primitives tested at the start of
+ * the ray buy?  Its own SAH tree (TOPBIG=1: without the spheres whose leaf box covers more than half of the root's surface —
+ * those are tested before the walk, so the walk starts with their hit as its `closest`), node boxes as the kernel holds them
+ * (HALF16=1: rounded outward to binary16), and the distance-aware growth by one of three rules:
+ *   GROW=1  dyn_k D^2, D = distance from the origin to the farthest corner of the UNION of the two children (step_pair_dyn)
+ *   GROW=2  dyn_k (T |d| + rho + e)^2, T = the exit parameter of the (grown, clipped) box the node was entered through, e the growth
+ *           it was tested with (every accepted hit below the node lies on the ray inside that box, so T |d| bounds its distance)
+ *   GROW=3  per child, farthest corner of the child's own box (box_test above)
+ *   GROW=0  none (the leaf boxes carry static margins) */
+static snode *g_m; static int g_mn; static float *g_mbox;      /* node boxes as walked */
+static int g_grow, g_half16, g_topbig, *g_top, g_ntop;
+static float g_rho;
+static unsigned long long m_pairs, m_leaf, m_top, m_mismatch, m_flag, m_mismatch_unflagged, m_pops;
+static float down16(float x) { if (x == 0 || !isfinite(x)) return x; int e; frexpf(x, &e); const float q = ldexpf(1.0f, e - 11); return floorf(x / q) * q; }
+static float up16(float x) { if (x == 0 || !isfinite(x)) return x; int e; frexpf(x, &e); const float q = ldexpf(1.0f, e - 11); return ceilf(x / q) * q; }
+static void planes_of(const float *box, const ray *r, float nr[3], float fr[3], float ainv[3]) {
+    for (int a = 0; a < 3; a++) {
+        float inv = 1 / r->d.e[a];
+        inv = fminf(fmaxf(inv, -1e18f), 1e18f);
+        const float noi = -(r->o.e[a] * inv);
+        const float ta = fmaf(box[2 * a], inv, noi), tb = fmaf(box[2 * a + 1], inv, noi);
+        nr[a] = fminf(ta, tb); fr[a] = fmaxf(ta, tb); ainv[a] = fabsf(inv);
+    }
+}
+static void model_ray(const ray *r, float c_ref, int prim_ref) {
+    float c = 1e30f; int p = -1, flag = 0;
+    for (int k = 0; k < g_ntop; k++) {
+        hitrec tmp; m_top++;
+        if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[g_top[k]])) { if (tmp.t == c && p >= 0) flag = 1; c = tmp.t; p = g_top[k]; }
+    }
+    struct { int idx; float e; } stack[128]; int sp = 0;
+    const float dlen = sqrtf(lensq(r->d)) * 1.000001f;
+    int cur = g_mn > 0 ? 0 : -1;
+    float e_cur = 0;
+    if (cur >= 0 && g_grow == 2) {      /* the root: farthest corner, once per ray */
+        float d2 = 0; const float *b = g_mbox;
+        for (int a = 0; a < 3; a++) { const float m = fmaxf(fabsf(r->o.e[a] - b[2 * a]), fabsf(b[2 * a + 1] - r->o.e[a])); d2 = fmaf(m, m, d2); }
+        e_cur = g_dynk * d2;
+        /* … or, with a hit already in hand, what its distance allows */
+        const float alt = g_dynk * (c * dlen + g_rho) * (c * dlen + g_rho) * 1.001f;
+        if (alt < e_cur) e_cur = alt;
+    }
+    if (cur >= 0 && g_m[0].left < 0) { hitrec tmp; m_leaf++; if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[g_m[0].prim])) { c = tmp.t; p = g_m[0].prim; } cur = -1; }
+    while (cur >= 0) {
+        const snode *n = &g_m[cur];
+        int next = -1; float e_next = 0;
+        if (n->left < 0) {
+            hitrec tmp; m_leaf++;
+            if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[n->prim])) { if (tmp.t == c && p >= 0) flag = 1; c = tmp.t; p = n->prim; }
+        } else {
+            m_pairs++;
+            const float t_far = c * (1.0f + 9.5367431640625e-7f);
+            const float *b0 = g_mbox + 6 * n->left, *b1 = g_mbox + 6 * n->right;
+            float n0[3], f0[3], n1[3], f1[3], ai[3];
+            planes_of(b0, r, n0, f0, ai); planes_of(b1, r, n1, f1, ai);
+            float g0 = 0, g1 = 0;
+            if (g_grow == 1) {
+                float d2 = 0;
+                for (int a = 0; a < 3; a++) { const float m = fmaxf(fmaxf(fabsf(n0[a]), fabsf(n1[a])), fmaxf(fabsf(f0[a]), fabsf(f1[a]))) * fmaxf(fabsf(r->d.e[a]), 1e-18f); d2 = fmaf(m, m, d2); }
+                g0 = g1 = g_dynk * 1.0009765625f * d2;
+            } else if (g_grow == 3) {
+                for (int k = 0; k < 2; k++) { const float *b = k ? b1 : b0; float d2 = 0;
+                    for (int a = 0; a < 3; a++) { const float m = fmaxf(fabsf(r->o.e[a] - b[2 * a]), fabsf(b[2 * a + 1] - r->o.e[a])); d2 = fmaf(m, m, d2); }
+                    if (k) g1 = g_dynk * d2; else g0 = g_dynk * d2; }
+            } else if (g_grow == 2) g0 = g1 = e_cur;
+            float e0 = 0.001f, q0 = t_far, e1 = 0.001f, q1 = t_far;
+            for (int a = 0; a < 3; a++) {
+                e0 = fmaxf(e0, n0[a] - g0 * ai[a]); q0 = fminf(q0, f0[a] + g0 * ai[a]);
+                e1 = fmaxf(e1, n1[a] - g1 * ai[a]); q1 = fminf(q1, f1[a] + g1 * ai[a]);
+            }
+            const int h0 = q0 > e0, h1 = q1 > e1;
+            const int second_first = h1 && !(h0 && e0 <= e1);
+            const int near_c = second_first ? n->right : n->left, far_c = second_first ? n->left : n->right;
+            const float q_near = second_first ? q1 : q0;
+            if (h0 && h1) { stack[sp].idx = far_c; stack[sp++].e = e_cur; }
+            if (h0 || h1) {
+                next = near_c;
+                if (g_grow == 2) { const float D = fmaf(q_near, dlen, g_rho) + e_cur; e_next = g_dynk * 1.0009765625f * D * D; if (e_next > e_cur) e_next = e_cur; }
+            }
+        }
+        if (next < 0) { if (sp == 0) break; --sp; next = stack[sp].idx; e_next = stack[sp].e; m_pops++;
+            if (g_grow == 2) { const float D = fmaf(c, dlen, g_rho) + e_next; const float alt = g_dynk * 1.0009765625f * D * D; if (alt < e_next) e_next = alt; } }
+        cur = next; e_cur = e_next;
+    }
+    if (p >= 0) { float e; const int h = aabb_hit_e(g_rbox + 6 * p, r, 0.001f, 1e30f, &e); if (!h || c <= e) flag = 1; }
+    m_flag += flag;
+    const int mm = (p != prim_ref) || (p >= 0 && c != c_ref);
+    m_mismatch += mm;
+    if (mm && !flag) { m_mismatch_unflagged++; if (m_mismatch_unflagged < 10) fprintf(stderr, "MODEL UNFLAGGED MISMATCH: ref prim %d t %.9g  got prim %d t %.9g\n", prim_ref, c_ref, p, c); }
+}
+static void model_setup(const rt_scene_desc *sc) {
+    g_grow = getenv("GROW") ? atoi(getenv("GROW")) : 1;
+    g_half16 = getenv("HALF16") != NULL; g_topbig = getenv("TOPBIG") != NULL;
+    /* root box of everything */
+    float rb[6] = {1e30f, -1e30f, 1e30f, -1e30f, 1e30f, -1e30f};
+    for (int i = 0; i < sc->num_spheres; i++) grow(rb, g_pbox + 6 * i);
+    int *ids = malloc(sizeof(int) * sc->num_spheres), n = 0;
+    g_top = malloc(sizeof(int) * sc->num_spheres);
+    float rmax_small = 0;
+    for (int i = 0; i < sc->num_spheres; i++) {
+        if (g_topbig && area(g_pbox + 6 * i) > 0.5f * area(rb)) g_top[g_ntop++] = i; else ids[n++] = i;
+        if (sc->spheres[i].radius < 100 && sc->spheres[i].radius > rmax_small) rmax_small = sc->spheres[i].radius;
+    }
+    g_rho = rmax_small * 1.001f;
+    snode *save = g_s; const int save_n = g_sn;
+    g_m = malloc(sizeof(snode) * 2 * (n + 1)); g_s = g_m; g_sn = 0;
+    if (n > 0) sah_build(ids, n);
+    g_mn = g_sn; g_s = save; g_sn = save_n;
+    g_mbox = malloc(sizeof(float) * 6 * (g_mn + 1));
+    for (int i = 0; i < g_mn; i++) for (int a = 0; a < 3; a++) {
+        g_mbox[6 * i + 2 * a] = g_half16 ? down16(g_m[i].box[2 * a]) : g_m[i].box[2 * a];
+        g_mbox[6 * i + 2 * a + 1] = g_half16 ? up16(g_m[i].box[2 * a + 1]) : g_m[i].box[2 * a + 1];
+    }
+    g_model_on = 1;
+    printf("MODEL: grow %d half16 %d topbig %d (%d primitives tested before the walk), tree of %d nodes, rho %.4g dyn_k %.4g\n", g_grow, g_half16, g_topbig, g_ntop, g_mn, g_rho, g_dynk);
+}
 static float fill_rmax(int i) {
     if (g_s[i].left < 0) return g_rmax[i] = g_scn->spheres[g_s[i].prim].radius;
     const float a = fill_rmax(g_s[i].left), b = fill_rmax(g_s[i].right);
@@ -445,6 +564,7 @@ int main(int argc, char **argv) {
     if (getenv("DEFER")) { g_defer = atoi(getenv("DEFER")); g_defer_on = 1; }
     if (getenv("LEAFK")) { g_leafk = atoi(getenv("LEAFK")); g_kids = malloc(sizeof(int) * sc.num_spheres); for (int i = 0; i < sc.num_spheres; i++) g_kids[i] = i;
         g_k = malloc(sizeof(knode) * 2 * sc.num_spheres); g_kn = 0; leafk_build(g_kids, sc.num_spheres); g_leafk_on = 1; printf("LEAFK tree: %d nodes\n", g_kn); }
+    if (getenv("MODEL")) model_setup(&sc);
     if (getenv("WIDE")) { g_w = calloc(g_sn, sizeof(wnode)); wide_build(0); g_w_any = g_w; }
     float *fb = malloc((size_t)W * H * 3 * sizeof(float));
     orc_render(&sc, &cam, 0, H, fb, 1, NULL);
@@ -467,6 +587,8 @@ int main(int argc, char **argv) {
                            (double)df_pairs / n_rays, (double)df_leaf / n_rays, df_mismatch);
     if (g_leafk_on) printf("LEAFK=%d: pair steps/ray %.2f (bottom pairs %.2f)  leaf visits/ray %.2f  discriminants/ray %.2f  reaching roots/ray %.2f  mismatches (unguarded) %llu\n", g_leafk,
                            (double)k_pairs / n_rays, (double)k_bottom / n_rays, (double)k_visits / n_rays, (double)k_disc / n_rays, (double)k_roots / n_rays, k_mismatch);
+    if (g_model_on) printf("MODEL: pair steps/ray %.2f  leaf tests/ray %.2f (+ %.2f before the walk)  pops/ray %.2f  flagged %.4f%%  mismatches %llu (unflagged %llu)\n", (double)m_pairs / n_rays,
+                           (double)m_leaf / n_rays, (double)m_top / n_rays, (double)m_pops / n_rays, 100.0 * m_flag / n_rays, m_mismatch, m_mismatch_unflagged);
     printf("  max pending-stack depth per ray:");
     for (int i = 0; i < 24; i++) if (depth_hist[i]) printf(" %d:%.4f%%", i, 100.0 * depth_hist[i] / n_rays);
     printf("\n");
