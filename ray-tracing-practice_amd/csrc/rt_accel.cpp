@@ -540,6 +540,7 @@ void Packer::prepare_guard() {
                 g.cluster_radius = static_cast<float>(rs * (1.0 + 1e-6));
                 g.far_k = static_cast<float>(gamma / (2.0 * r_min_small) * (1.0 + 1e-6));
                 g.dyn_k = dynamic ? static_cast<float>(gamma / (2.0 * r_min_small) * (1.0 + 4e-6)) : 0.0f;
+                g.dyn_rmax = dynamic ? static_cast<float>(r_max_small * (1.0 + 1e-6)) : 0.0f;
                 for (int i = 0; i < d.num_spheres; ++i) {
                     if (leaf_of_sphere[static_cast<size_t>(i)] < 0 || large[static_cast<size_t>(i)]) continue;
                     const float *b = d.nodes[leaf_of_sphere[static_cast<size_t>(i)]].box;
@@ -689,6 +690,11 @@ void Packer::pair_tables() {
         return (c & 1) ? plane_box[static_cast<size_t>(c >> 1)] : sphere_box[static_cast<size_t>(c >> 1)];
     };
     out.num_internal = static_cast<int32_t>(bnodes.size());
+    // (every inner node of a tree built here has two children — step_pair_dyn relies on it; the caller-topology tree of
+    // TreeMode::Reference may carry untyped leaves as empty slots, and no guarded kernel walks that one)
+    out.full_pairs = true;
+    for (const BuildNode &b : bnodes)
+        if (b.child[0] == kTraversalDone || b.child[1] == kTraversalDone) out.full_pairs = false;
     out.nodes.resize(bnodes.size() * 16);
     for (size_t k = 0; k < bnodes.size(); ++k) {
         float *o = &out.nodes[k * 16];
@@ -873,6 +879,10 @@ std::string pack_scene(const rt_scene_desc &d, TreeMode mode, Packed &out, const
     pk.prepare_guard();
     pk.build_tree();
     pk.pair_tables();
+    if (mode == TreeMode::Guarded && out.guard.ok && !out.full_pairs) {      // (cannot happen: the SAH build splits every range in two)
+        out.guard.ok = false;
+        out.guard.reason = "traversal tree with an empty child slot";
+    }
     return pk.primitive_tables();
 }
 

@@ -49,6 +49,7 @@ struct Packed {
     int32_t num_top = 0, xroot = 0;
     int32_t root = kTraversalDone; // node code of the root (leaf code when the scene has one primitive)
     int32_t num_internal = 0;
+    bool full_pairs = true;        // no inner node has an empty child slot (kTraversalDone)
     int32_t num_top_pairs = 0;     // Guarded: nodes [0, num_top_pairs) are the top of the tree, breadth-first
     int32_t max_depth = 0;         // longest root→leaf path in internal nodes = traversal stack bound
     // Guarded, host-built tree: the same tree collapsed to 4-wide nodes (layout in rt_accel.cpp); empty when the root is a leaf
@@ -71,6 +72,7 @@ struct Packed {
         // test of the walk grows its box by dyn_k * (distance from the ray origin to the box's farthest corner)^2
         // >= gamma |o - c_q|^2 / (2 r_q) for every small sphere q below — no assumption about where rays start.
         float dyn_k = 0;
+        float dyn_rmax = 0;            // … and the largest radius among those small spheres (the parametric form of the growth, step_pair_par)
         int32_t num_small = 0, num_large = 0;
         // every margin assumes ray origins within origin_radius of origin_center (all scene surfaces +
         // 25 %): the camera position is checked against it per render

@@ -231,6 +231,24 @@ rt_status upload(const std::vector<T> &host, void **dev) {
     return RT_OK;
 }
 
+// step_pair_dyn (rt_kernel.hip.inc) adds a record's 32-bit byte offset to the LOW word of the binary16 pair table's address:
+// the table must not straddle a 4 GiB line.  One that does (a few MB in a 4 GiB window: one allocation in a thousand) is
+// moved — the replacement is allocated while the original still holds its address.
+rt_status settle_table(float4 **table, size_t bytes) {
+    auto straddles = [bytes](const void *p) { return (((uintptr_t)p & 0xffffffffull) + bytes) > 0x100000000ull; };
+    std::vector<void *> bad;
+    rt_status st = RT_OK;
+    while (*table && bytes && straddles(*table)) {
+        void *fresh = nullptr;
+        if (bad.size() >= 8 || hipMalloc(&fresh, bytes) != hipSuccess) { st = fail(RT_ERR_OUT_OF_MEMORY, "no placement of the pair table inside one 4 GiB window"); break; }
+        if (hipMemcpy(fresh, *table, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(fresh); st = fail(RT_ERR_HIP, "copy of the pair table failed"); break; }
+        bad.push_back(*table);
+        *table = (float4 *)fresh;
+    }
+    for (void *b : bad) (void)hipFree(b);
+    return st;
+}
+
 // Reciprocal for div_magic(): exact quotients for every n <= n_max (checked, not assumed).
 bool make_magic(uint32_t d, uint64_t n_max, rtk::Magic &g) {
     if (d == 0) return false;
@@ -329,6 +347,11 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.g_rs = sc->guard.cluster_radius;
     P.g_fark = sc->guard.far_k;
     P.g_dynk = sc->guard.dyn_k;
+    {   // step_pair_par: sqrt(k) with the walk's slack, and sqrt(k) sqrt(3) r_max — both rounded up
+        const double sk = std::sqrt((double)sc->guard.dyn_k * (double)rtk::kDynSlack) * (1.0 + 1e-6);
+        P.g_dyn_sqrtk = std::nextafterf((float)sk, INFINITY);
+        P.g_dyn_b = std::nextafterf((float)(sk * 1.7320508075688772 * (double)sc->guard.dyn_rmax * (1.0 + 1e-6)), INFINITY);
+    }
     P.num_front = sc->guard.num_front;
     std::memcpy(P.front_code, sc->guard.front_code, sizeof(P.front_code));
     std::memcpy(P.front_box, sc->guard.front_box, sizeof(P.front_box));
@@ -367,6 +390,10 @@ rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream
     if ((st = upload(pk.nodes, (void **)&nodes)) != RT_OK || (st = upload(pk.hnodes, (void **)&hnodes)) != RT_OK ||
         (st = upload(pk.wnodes, (void **)&wnodes)) != RT_OK || (st = upload(pk.whnodes, (void **)&whnodes)) != RT_OK ||
         (st = upload(pk.leaf_boxes, (void **)&leaf_boxes)) != RT_OK || (st = upload(pk.plane_leaf_boxes, (void **)&plane_leaf_boxes)) != RT_OK) {
+        (void)hipFree(nodes); (void)hipFree(hnodes); (void)hipFree(wnodes); (void)hipFree(whnodes); (void)hipFree(leaf_boxes); (void)hipFree(plane_leaf_boxes);
+        return st;
+    }
+    if ((st = settle_table(&hnodes, (size_t)pk.num_internal * 32)) != RT_OK) {
         (void)hipFree(nodes); (void)hipFree(hnodes); (void)hipFree(wnodes); (void)hipFree(whnodes); (void)hipFree(leaf_boxes); (void)hipFree(plane_leaf_boxes);
         return st;
     }
@@ -539,6 +566,7 @@ rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cf
         if ((st = upload(pk.whnodes, (void **)&sc->whnodes)) != RT_OK) return bail(st);
         sc->num_wide = pk.num_wide; sc->num_top_wide = pk.num_top_wide; sc->wroot = pk.wroot; sc->wide_depth = pk.wide_depth;
     }
+    if ((st = settle_table(&sc->hnodes, (size_t)pk.num_internal * 32)) != RT_OK) return bail(st);
     if ((st = upload(pk.tnodes, (void **)&sc->tnodes)) != RT_OK) return bail(st);
     sc->num_tnodes = pk.num_tnodes;
     if ((st = upload(pk.xnodes, (void **)&sc->xnodes)) != RT_OK) return bail(st);
@@ -861,15 +889,21 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             while (fast.wgs_per_cu > 1 && fast.stack_levels < min_levels) fast.stack_levels = levels_for(table_bytes, --fast.wgs_per_cu);
             if (fast.stack_levels < min_levels) fast.in_lds = false;
         }
+        // (step_pair_dyn / step_pair_par, the walk of big scenes with distance-aware margins, keep a sentinel in level 0 — one level
+        // more for the same twelve entries — and step_pair_par two rows of per-ray values behind the stack)
+        const bool dyn_pair = !fast.in_lds && sc->guard.dyn_k > 0.0f && !wide && !want_wavefront && RTP_DYN_ROTATE != 0;
+        const int32_t extra_rows = dyn_pair ? (RTP_DYN_PARAM != 0 ? 2 : 0) : 0;
         if (!fast.in_lds) {
             // tables through L1/L2: a 12-entry stack per lane (deeper ones are rare enough to flag), the rest of
             // the workgroup's LDS share holds the top of the tree
             fast.wgs_per_cu = gwgs_per_cu;
-            fast.stack_levels = levels_for(0, fast.wgs_per_cu);
-            if (fast.stack_levels > 12) fast.stack_levels = 12;
+            const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
+            const int64_t fit = budget > pool_bytes ? (int64_t)((budget - pool_bytes) / per_level) : 0;
+            const int32_t cap = (dyn_pair ? 13 : 12) + extra_rows;
+            fast.stack_levels = (int32_t)std::min<int64_t>(std::min<int64_t>(fit, want + extra_rows), cap);
         }
-        if (const int forced = cfg.stack_levels) fast.stack_levels = forced < fast.stack_levels ? forced : fast.stack_levels;
-        if (fast.stack_levels < (want < 2 ? want : 2)) guarded = false;
+        if (const int forced = cfg.stack_levels) fast.stack_levels = forced + extra_rows < fast.stack_levels ? forced + extra_rows : fast.stack_levels;
+        if (fast.stack_levels - extra_rows < (want < 2 ? want : 2)) guarded = false;
         if (!fast.in_lds && cfg.lds_treelet) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);

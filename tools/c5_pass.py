@@ -5,7 +5,7 @@ import rtp_bindings as rb, numpy as np, ctypes as C
 rb.HONOUR_ENV = True
 import torch
 spp=int(os.environ.get('SPP',125))
-hs=rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=2048)
+hs=rb.HostScene.rtiow(half_extent=158, textured_quad=True, texture_size=int(os.environ.get("TEXSIZE",2048)))
 cam=rb.rtiow_camera(3840,2160,spp,50)
 ds=rb.DeviceScene(hs,device=0, **eval(os.environ.get('KW','{}')))
 fb=torch.zeros((2160,3840,3),dtype=torch.float32,device='cuda:0')

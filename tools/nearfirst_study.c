@@ -410,13 +410,15 @@ static void model_ray(const ray *r, float c_ref, int prim_ref) {
     const float dlen = sqrtf(lensq(r->d)) * 1.000001f;
     int cur = g_mn > 0 ? 0 : -1;
     float e_cur = 0;
-    if (cur >= 0 && g_grow == 2) {      /* the root: farthest corner, once per ray */
+    float e_root = 0;
+    if (cur >= 0 && (g_grow == 2 || g_grow == 4)) {      /* the root: farthest corner, once per ray */
         float d2 = 0; const float *b = g_mbox;
         for (int a = 0; a < 3; a++) { const float m = fmaxf(fabsf(r->o.e[a] - b[2 * a]), fabsf(b[2 * a + 1] - r->o.e[a])); d2 = fmaf(m, m, d2); }
         e_cur = g_dynk * d2;
         /* … or, with a hit already in hand, what its distance allows */
         const float alt = g_dynk * (c * dlen + g_rho) * (c * dlen + g_rho) * 1.001f;
         if (alt < e_cur) e_cur = alt;
+        e_root = e_cur;
     }
     if (cur >= 0 && g_m[0].left < 0) { hitrec tmp; m_leaf++; if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[g_m[0].prim])) { c = tmp.t; p = g_m[0].prim; } cur = -1; }
     while (cur >= 0) {
@@ -440,7 +442,7 @@ static void model_ray(const ray *r, float c_ref, int prim_ref) {
                 for (int k = 0; k < 2; k++) { const float *b = k ? b1 : b0; float d2 = 0;
                     for (int a = 0; a < 3; a++) { const float m = fmaxf(fabsf(r->o.e[a] - b[2 * a]), fabsf(b[2 * a + 1] - r->o.e[a])); d2 = fmaf(m, m, d2); }
                     if (k) g1 = g_dynk * d2; else g0 = g_dynk * d2; }
-            } else if (g_grow == 2) g0 = g1 = e_cur;
+            } else if (g_grow == 2 || g_grow == 4) g0 = g1 = e_cur;
             float e0 = 0.001f, q0 = t_far, e1 = 0.001f, q1 = t_far;
             for (int a = 0; a < 3; a++) {
                 e0 = fmaxf(e0, n0[a] - g0 * ai[a]); q0 = fminf(q0, f0[a] + g0 * ai[a]);
@@ -453,11 +455,12 @@ static void model_ray(const ray *r, float c_ref, int prim_ref) {
             if (h0 && h1) { stack[sp].idx = far_c; stack[sp++].e = e_cur; }
             if (h0 || h1) {
                 next = near_c;
-                if (g_grow == 2) { const float D = fmaf(q_near, dlen, g_rho) + e_cur; e_next = g_dynk * 1.0009765625f * D * D; if (e_next > e_cur) e_next = e_cur; }
+                if (g_grow == 2 || g_grow == 4) { const float D = fmaf(q_near, dlen, g_rho) + e_cur; e_next = g_dynk * 1.0009765625f * D * D; if (e_next > e_cur) e_next = e_cur; }
             }
         }
         if (next < 0) { if (sp == 0) break; --sp; next = stack[sp].idx; e_next = stack[sp].e; m_pops++;
-            if (g_grow == 2) { const float D = fmaf(c, dlen, g_rho) + e_next; const float alt = g_dynk * 1.0009765625f * D * D; if (alt < e_next) e_next = alt; } }
+            if (g_grow == 4) e_next = e_root;
+            if (g_grow == 2 || g_grow == 4) { const float D = fmaf(c, dlen, g_rho) + e_next; const float alt = g_dynk * 1.0009765625f * D * D; if (alt < e_next) e_next = alt; } }
         cur = next; e_cur = e_next;
     }
     if (p >= 0) { float e; const int h = aabb_hit_e(g_rbox + 6 * p, r, 0.001f, 1e30f, &e); if (!h || c <= e) flag = 1; }
