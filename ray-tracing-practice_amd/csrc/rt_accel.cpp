@@ -594,6 +594,12 @@ void Packer::prepare_guard() {
                 g.num_front++;
                 leaves.erase(leaves.begin() + static_cast<std::ptrdiff_t>(big));
             }
+            // planes first (the cheaper test)
+            for (int a = 1; a < g.num_front; ++a)
+                for (int b = a; b > 0 && (g.front_code[b] & 1) && !(g.front_code[b - 1] & 1); --b) {
+                    std::swap(g.front_code[b], g.front_code[b - 1]);
+                    for (int k = 0; k < 6; ++k) std::swap(g.front_box[b][k], g.front_box[b - 1][k]);
+                }
         }
         g.reason = why;
     }

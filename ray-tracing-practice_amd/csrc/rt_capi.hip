@@ -904,7 +904,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         }
         if (const int forced = cfg.stack_levels) fast.stack_levels = forced + extra_rows < fast.stack_levels ? forced + extra_rows : fast.stack_levels;
         if (fast.stack_levels - extra_rows < (want < 2 ? want : 2)) guarded = false;
-        if (!fast.in_lds && cfg.lds_treelet) {
+        // (step_pair_par reads every record through L1 / L2: RTP_DYN_TOP)
+        if (!fast.in_lds && cfg.lds_treelet && !(dyn_pair && RTP_DYN_PARAM != 0 && RTP_DYN_TOP == 0)) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);
             const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;

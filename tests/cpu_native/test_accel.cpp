@@ -221,7 +221,7 @@ int main() {
         CHECK(rtaccel::pack_scene(with_plane.desc(), rtaccel::TreeMode::Guarded, pk).empty());
         CHECK(pk.guard.ok && pk.plane_leaf_boxes.size() == with_plane.planes.size() * 8 && pk.num_tnodes > 0);
         // the ground sphere, then the floor quad under the field of small spheres (half of what is left once the ground is out)
-        CHECK(pk.guard.num_front == 2 && pk.guard.front_code[0] == 0 && pk.guard.front_code[1] == 1);
+        CHECK(pk.guard.num_front == 2 && pk.guard.front_code[0] == 1 && pk.guard.front_code[1] == 0);       // (the plane first)
         {
             std::vector<rt_plane> planes(with_plane.planes);
             rt_scene_desc dp = with_plane.desc();
