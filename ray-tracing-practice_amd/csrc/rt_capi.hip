@@ -883,7 +883,12 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         };
         const int32_t min_levels = want < 4 ? want : 4;          // a shorter stack flags too many rays
         fast.wgs_per_cu = gwgs_per_cu;
-        fast.in_lds = cfg.scene_in_lds != 0;
+        // Scenes with distance-aware margins always take their records through L1 / L2 (step_pair_par: 32-byte binary16 records, a
+        // full stack, two workgroups per CU whatever the size of the tree).  The LDS-resident form of that walk lost on every
+        // random scene it was tried on — tables of a thousand nodes leave room for one workgroup per CU or for a stack of four,
+        // and the rays a short stack hands to the exact walk cost more than L1 does: tools/_dyn_probe.py, docs/LOG.md round 4.
+        const bool dyn_global = sc->guard.dyn_k > 0.0f && !wide && !want_wavefront && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
+        fast.in_lds = cfg.scene_in_lds != 0 && !dyn_global;
         if (fast.in_lds) {
             fast.stack_levels = levels_for(table_bytes, fast.wgs_per_cu);
             while (fast.wgs_per_cu > 1 && fast.stack_levels < min_levels) fast.stack_levels = levels_for(table_bytes, --fast.wgs_per_cu);
@@ -1275,11 +1280,11 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
                 } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, false, true>, P, wgs, fast.lds_bytes));
 #endif
-            } else if (dyn && prim) {
-                if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true, false, false, true>, P, wgs, fast.lds_bytes));
-                else HIP_TRY(launch(rtk::render_kernel<false, false, true, false, false, true>, P, wgs, fast.lds_bytes));
+            } else if (dyn && fast.in_lds) {       // (only with RTP_DYN_PARAM or RTP_DYN_ROTATE off: developer variants)
+                if (prim) HIP_TRY(launch(rtk::render_kernel<true, false, true, false, false, true>, P, wgs, fast.lds_bytes));
+                else HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
             } else if (dyn) {
-                if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
+                if (prim) HIP_TRY(launch(rtk::render_kernel<false, false, true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true>, P, wgs, fast.lds_bytes));
             } else if (fast.in_lds && simple && prim) HIP_TRY(launch_simple(rtk::render_kernel<true, false, false, false, true, true>, P, wgs, fast.lds_bytes));
             else if (fast.in_lds && simple) HIP_TRY(launch_simple(rtk::render_kernel<true, false, false, false, true>, P, wgs, fast.lds_bytes));
