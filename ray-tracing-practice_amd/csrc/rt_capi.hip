@@ -204,6 +204,9 @@ struct rt_scene {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_listed = nullptr;
     uint32_t *cand = nullptr;       // primary visibility: per local pixel rtk::kCandWords words (candidate leaves), grown on demand
     size_t cand_pixels = 0;
+    // what the lists in `cand` (and the fetch order behind them) were made for: a call with the same view of the same tree on the
+    // same stream — the next sample batch of a progressive render, the next frame of a still — reuses them (0.4 ms at 1080p)
+    struct CandKey { float view[12]; int32_t dims[9]; int repacks; hipStream_t stream; bool valid = false; } cand_key;
     float4 *wf_pool = nullptr;      // render_kernel_wf: ray/hit stacks of every resident wave, grown on demand
     size_t wf_pool_float4s = 0;
     int32_t num_internal = 0, num_spheres = 0, num_planes = 0, num_materials = 0, root = rtk::kDone, tree_depth = 0;
@@ -1068,6 +1071,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         (void)hipFree(sc->cand);
         sc->cand = nullptr;
         sc->cand_pixels = 0;
+        sc->cand_key.valid = false;
         // (64 bytes per pixel; a device short of memory renders without the pass rather than not at all)
         // + 4 bytes per pixel for the fetch order and 12 per 256 pixels for its counting sort (order_* kernels)
         const size_t cand_words = (size_t)num_pixels * (rtk::kCandWords + 1) + 3 * (((size_t)num_pixels + rtk::kOrderBlock - 1) / rtk::kOrderBlock);
@@ -1086,7 +1090,18 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     if ((st = acquire_feedback(sc, &feedback)) != RT_OK) return st;
     HIP_TRY(hipEventRecord(feedback->start, stream));
     HIP_TRY(hipEventRecord(sc->ev_start, stream));
+    rt_scene::CandKey key{};
     if (prim) {
+        std::memcpy(key.view + 0, cam->origin.e, 12); std::memcpy(key.view + 3, cam->pixel00_loc.e, 12);
+        std::memcpy(key.view + 6, cam->pixel_delta_u.e, 12); std::memcpy(key.view + 9, cam->pixel_delta_v.e, 12);
+        const int32_t dims[9] = {P.width, P.height, P.local_rows, P.band_rows, P.num_parts, P.part, P.row_w, P.tile_x0, P.tile_y0};
+        std::memcpy(key.dims, dims, sizeof(dims));
+        key.repacks = sc->repacks; key.stream = stream; key.valid = true;
+    }
+    const bool cand_cached = prim && sc->cand_key.valid && std::memcmp(key.view, sc->cand_key.view, sizeof(key.view)) == 0 &&
+                             std::memcmp(key.dims, sc->cand_key.dims, sizeof(key.dims)) == 0 && key.repacks == sc->cand_key.repacks && key.stream == sc->cand_key.stream;
+    if (!cand_cached) sc->cand_key.valid = false;          // (valid again once the launches below are queued)
+    if (prim && !cand_cached) {
         const double coord_max = rtbeam::coord_bound(cam->origin.e, cam->pixel00_loc.e, cam->pixel_delta_u.e, cam->pixel_delta_v.e, cam->image_width, cam->image_height);
         hipLaunchKernelGGL(rtk::cand_kernel, dim3((num_pixels + 255u) / 256u), dim3(256), 0, stream, P, sc->cand, coord_max);
         HIP_TRY(hipGetLastError());
@@ -1098,6 +1113,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         hipLaunchKernelGGL(rtk::order_scatter_kernel, dim3(order_blocks), dim3(rtk::kOrderBlock), 0, stream, (const uint32_t *)sc->cand, num_pixels, order_blocks,
                            (const uint32_t *)counts, order);
         HIP_TRY(hipGetLastError());
+        sc->cand_key = key;
     }
     hipStream_t launch_stream = stream;       // the exact re-walk may go to the handle's second stream (overlap_rework)
     // registers and scratch of the dominant (trace) kernel as the loaded code object reports them → rt_timing

@@ -770,6 +770,30 @@ def test_sphere_only_kernel_and_general_kernel_give_the_same_frame():
     assert t3.sphere_only == 0
 
 
+def test_candidate_lists_are_reused_for_the_same_view(rtiow):
+    """The per-pixel candidate lists and the fetch order are kept with the handle: a call with the same camera, image, shard and
+    tree on the same stream (the next batch of a progressive render) does not make them again, any other call does — frames are the
+    oracle's in every order of views."""
+    host, _ = rtiow
+    dev = rb.DeviceScene(host, device=0, honour_env=False)
+    a, b = rb.rtiow_camera(160, 90, 8, 50), rb.make_camera(160, 90, 35.0, (-9, 4, 6), (0, 0.5, 0), (0.7, 0.8, 1.0), 8, 50)
+    more = rb.rtiow_camera(160, 90, 20, 50)        # the view of `a`, more samples: the lists do not depend on the sample count
+    want = {id(c): ob.render(host, c, threads=8) for c in (a, b, more)}
+    times = []
+    for cam in (a, a, b, a, more, more):
+        fb, t = dev.render_to_host(cam)
+        assert t.guarded == 1 and t.primary_visibility == 1
+        assert_same_frame(fb, want[id(cam)], "view sequence")
+        times.append(t.primary_ms)
+    shard = rb.Shard(8, 2, 1)
+    for _ in range(2):
+        fb, t = dev.render_to_host(a, shard)
+        rows = np.concatenate([want[id(a)][r:r + 8] for r in range(8, 90, 16)])
+        assert_same_frame(fb, rows, "row shard of the same view")
+    # (a repeated view — the second call, and `more` after `a` — costs the per-sample pass alone)
+    assert times[1] < 0.5 * times[0] and times[4] < 0.5 * times[3] and times[5] < 0.5 * times[3], times
+
+
 def test_front_primitives_change_nothing_but_the_time(test_config_text):
     """rt_config.guard_front_primitives: primitives that span the scene (S-rtiow's ground sphere; the ground sphere and the
     floor quad of the textured scene; the floor of the reference's config scene) are not leaves of the guarded walk's tree —
