@@ -889,7 +889,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // Scenes with distance-aware margins always take their records through L1 / L2 (step_pair_par: 32-byte binary16 records, a
         // full stack, two workgroups per CU whatever the size of the tree).  The LDS-resident form of that walk lost on every
         // random scene it was tried on — tables of a thousand nodes leave room for one workgroup per CU or for a stack of four,
-        // and the rays a short stack hands to the exact walk cost more than L1 does: tools/_dyn_probe.py, docs/LOG.md round 4.
+        // and the rays a short stack hands to the exact walk cost more than L1 does: tools/dyn_probe.py, docs/LOG.md round 4.
         const bool dyn_global = sc->guard.dyn_k > 0.0f && !wide && !want_wavefront && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
         fast.in_lds = cfg.scene_in_lds != 0 && !dyn_global;
         if (fast.in_lds) {

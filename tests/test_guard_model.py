@@ -53,3 +53,25 @@ def test_every_order_sensitive_ray_is_flagged(study_binary, half_extent, width, 
         assert dep < 0.5                         # computed hits stay well inside the (statically) inflated boxes
     assert steps * 2 < visits                    # and the walk does pay: under half the box tests
     assert "UNFLAGGED MISMATCH" not in res.stderr
+
+
+@pytest.mark.parametrize("half_extent,width,height,spp,dyn", [(11, 192, 108, 6, False), (40, 200, 112, 4, True), (100, 192, 108, 3, True)])
+def test_front_primitives_and_parametric_growth(study_binary, half_extent, width, height, spp, dyn):
+    """Round 4, the model of what the kernels do now (MODEL=1): the scene-spanning primitive (the ground sphere) is tested
+    before the walk and is not a leaf of the tree (TOPBIG); with distance-aware margins the boxes — binary16, rounded outward —
+    grow by the PARAMETRIC rule of step_pair_par (GROW=4): from the exit parameter of the box a node was entered through.  Every
+    ray the oracle casts: a result that differs from hit_bvh's must have been flagged, and on every accepted hit of a small sphere
+    the growth its leaf's box was tested with covers k |o - c|^2 — the induction hypothesis the rule rests on."""
+    env = dict(os.environ, GAMMA_ULPS="24", MODEL="1", TOPBIG="1", GROW="4" if dyn else "0")
+    if dyn:
+        env.update(DYN="1", HALF16="1")
+    res = subprocess.run([study_binary, str(half_extent), str(width), str(height), str(spp)], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    m = re.search(r"MODEL: pair steps/ray ([0-9.]+)\s+leaf tests/ray ([0-9.]+) \(\+ ([0-9.]+) before the walk\).*mismatches (\d+) \(unflagged (\d+)\)\s+"
+                  r"growth bound checked on (\d+) hits, broken (\d+)", res.stdout)
+    assert m, res.stdout[-2000:]
+    pairs, front, unflagged, checked, broken = float(m.group(1)), float(m.group(3)), int(m.group(5)), int(m.group(6)), int(m.group(7))
+    assert front == 1.0 and unflagged == 0 and broken == 0
+    assert (checked > 50000) == dyn
+    old = float(re.search(r"SAH tree, near-first.*\(pair steps ([0-9.]+)\)", res.stdout).group(1))      # the walk with every primitive a leaf, corner growth
+    assert pairs < old

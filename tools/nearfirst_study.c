@@ -381,8 +381,11 @@ static void leafk_ray(const ray *r, float c_ref, int prim_ref) {
  * those are tested before the walk, so the walk starts with their hit as its `closest`), node boxes as the kernel holds them
  * (HALF16=1: rounded outward to binary16), and the distance-aware growth by one of three rules:
  *   GROW=1  dyn_k D^2, D = distance from the origin to the farthest corner of the UNION of the two children (step_pair_dyn)
- *   GROW=2  dyn_k (T |d| + rho + e)^2, T = the exit parameter of the (grown, clipped) box the node was entered through, e the growth
- *           it was tested with (every accepted hit below the node lies on the ray inside that box, so T |d| bounds its distance)
+ *   GROW=4  the kernel's rule (step_pair_par): k (T |d| + sqrt(3) (r_max + e))^2, T = the exit parameter of the (grown, clipped) box the
+ *           node was entered through, e the growth that box was tested with — every accepted hit below the node lies on the ray inside
+ *           that box, so T |d| bounds its distance; a node off the stack gets the ray's own bound (corner of the tree / the hit in hand).
+ *           Every accepted hit of a small sphere is checked against the induction hypothesis (growth of its box >= k |o - c|^2).
+ *   GROW=2  the same with the parent's growth kept on the stack for a popped node
  *   GROW=3  per child, farthest corner of the child's own box (box_test above)
  *   GROW=0  none (the leaf boxes carry static margins) */
 static snode *g_m; static int g_mn; static float *g_mbox;      /* node boxes as walked */
@@ -400,6 +403,10 @@ static void planes_of(const float *box, const ray *r, float nr[3], float fr[3], 
         nr[a] = fminf(ta, tb); fr[a] = fmaxf(ta, tb); ainv[a] = fabsf(inv);
     }
 }
+static unsigned long long m_inv_checked, m_inv_broken;
+/* the kernel's par_growth (rt_kernel.hip.inc): E(T, e) = (sqrt(k) |d| T + sqrt(k) sqrt(3) r_max + sqrt(k) sqrt(3) e)^2 */
+static float g_sqrtk, g_parb, g_parc3;
+static inline float par_growth(float T, float ea, float e) { const float s = fmaf(e, g_parc3, fmaf(T, ea, g_parb)); return s * s; }
 static void model_ray(const ray *r, float c_ref, int prim_ref) {
     float c = 1e30f; int p = -1, flag = 0;
     for (int k = 0; k < g_ntop; k++) {
@@ -407,26 +414,38 @@ static void model_ray(const ray *r, float c_ref, int prim_ref) {
         if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[g_top[k]])) { if (tmp.t == c && p >= 0) flag = 1; c = tmp.t; p = g_top[k]; }
     }
     struct { int idx; float e; } stack[128]; int sp = 0;
-    const float dlen = sqrtf(lensq(r->d)) * 1.000001f;
+    const int par = g_grow == 2 || g_grow == 4;
+    const float ea = g_sqrtk * 1.000002f * sqrtf(lensq(r->d));
     int cur = g_mn > 0 ? 0 : -1;
-    float e_cur = 0;
-    float e_root = 0;
-    if (cur >= 0 && (g_grow == 2 || g_grow == 4)) {      /* the root: farthest corner, once per ray */
+    float e_cur = 0, er = 0, tested_e = 1e30f;      /* tested_e: the growth the current node's own box was tested with */
+    if (cur >= 0 && par) {      /* arm_ray: the corner bound of the whole tree, or what a hit already in hand allows */
         float d2 = 0; const float *b = g_mbox;
         for (int a = 0; a < 3; a++) { const float m = fmaxf(fabsf(r->o.e[a] - b[2 * a]), fabsf(b[2 * a + 1] - r->o.e[a])); d2 = fmaf(m, m, d2); }
-        e_cur = g_dynk * d2;
-        /* … or, with a hit already in hand, what its distance allows */
-        const float alt = g_dynk * (c * dlen + g_rho) * (c * dlen + g_rho) * 1.001f;
-        if (alt < e_cur) e_cur = alt;
-        e_root = e_cur;
+        er = g_dynk * 1.0009765625f * d2;
+        er = fminf(er, par_growth(c, ea, er));
+        e_cur = er;
     }
     if (cur >= 0 && g_m[0].left < 0) { hitrec tmp; m_leaf++; if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[g_m[0].prim])) { c = tmp.t; p = g_m[0].prim; } cur = -1; }
     while (cur >= 0) {
         const snode *n = &g_m[cur];
-        int next = -1; float e_next = 0;
+        int next = -1; float e_next = 0, tested_next = 1e30f;
         if (n->left < 0) {
             hitrec tmp; m_leaf++;
-            if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[n->prim])) { if (tmp.t == c && p >= 0) flag = 1; c = tmp.t; p = n->prim; }
+            if (hit_sphere(r, 0.001f, c, &tmp, &g_scn->spheres[n->prim])) {
+                if (tmp.t == c && p >= 0) flag = 1;
+                c = tmp.t; p = n->prim;
+                if (par) {
+                    /* the induction hypothesis of step_pair_par, on this very hit: the growth the leaf's box was tested with
+                     * covers k |o - c_q|^2 (small spheres: the ones the growth exists for) */
+                    const rt_sphere *q = &g_scn->spheres[n->prim];
+                    if (q->radius < 100) {
+                        double x2 = 0; for (int a = 0; a < 3; a++) x2 += ((double)r->o.e[a] - q->center.e[a]) * ((double)r->o.e[a] - q->center.e[a]);
+                        m_inv_checked++;
+                        if ((double)g_dynk * x2 > (double)tested_e * (1.0 + 1e-5)) m_inv_broken++;
+                    }
+                    er = fminf(er, par_growth(c, ea, er));      /* the leaf step: the ray's own bound comes down with the hit */
+                }
+            }
         } else {
             m_pairs++;
             const float t_far = c * (1.0f + 9.5367431640625e-7f);
@@ -442,7 +461,7 @@ static void model_ray(const ray *r, float c_ref, int prim_ref) {
                 for (int k = 0; k < 2; k++) { const float *b = k ? b1 : b0; float d2 = 0;
                     for (int a = 0; a < 3; a++) { const float m = fmaxf(fabsf(r->o.e[a] - b[2 * a]), fabsf(b[2 * a + 1] - r->o.e[a])); d2 = fmaf(m, m, d2); }
                     if (k) g1 = g_dynk * d2; else g0 = g_dynk * d2; }
-            } else if (g_grow == 2 || g_grow == 4) g0 = g1 = e_cur;
+            } else if (par) g0 = g1 = e_cur;
             float e0 = 0.001f, q0 = t_far, e1 = 0.001f, q1 = t_far;
             for (int a = 0; a < 3; a++) {
                 e0 = fmaxf(e0, n0[a] - g0 * ai[a]); q0 = fminf(q0, f0[a] + g0 * ai[a]);
@@ -452,16 +471,15 @@ static void model_ray(const ray *r, float c_ref, int prim_ref) {
             const int second_first = h1 && !(h0 && e0 <= e1);
             const int near_c = second_first ? n->right : n->left, far_c = second_first ? n->left : n->right;
             const float q_near = second_first ? q1 : q0;
-            if (h0 && h1) { stack[sp].idx = far_c; stack[sp++].e = e_cur; }
+            if (h0 && h1) { stack[sp].idx = far_c; stack[sp++].e = e_cur; }       /* (e: what its box was tested with — for the check above) */
             if (h0 || h1) {
-                next = near_c;
-                if (g_grow == 2 || g_grow == 4) { const float D = fmaf(q_near, dlen, g_rho) + e_cur; e_next = g_dynk * 1.0009765625f * D * D; if (e_next > e_cur) e_next = e_cur; }
+                next = near_c; tested_next = e_cur;
+                if (par) e_next = fminf(e_cur, par_growth(q_near, ea, e_cur));
             }
         }
-        if (next < 0) { if (sp == 0) break; --sp; next = stack[sp].idx; e_next = stack[sp].e; m_pops++;
-            if (g_grow == 4) e_next = e_root;
-            if (g_grow == 2 || g_grow == 4) { const float D = fmaf(c, dlen, g_rho) + e_next; const float alt = g_dynk * 1.0009765625f * D * D; if (alt < e_next) e_next = alt; } }
-        cur = next; e_cur = e_next;
+        if (next < 0) { if (sp == 0) break; --sp; next = stack[sp].idx; tested_next = stack[sp].e; m_pops++;
+            e_next = g_grow == 2 ? fminf(stack[sp].e, er) : er; }      /* GROW=4 (the kernel): nothing but the node is kept on the stack */
+        cur = next; e_cur = e_next; tested_e = tested_next;
     }
     if (p >= 0) { float e; const int h = aabb_hit_e(g_rbox + 6 * p, r, 0.001f, 1e30f, &e); if (!h || c <= e) flag = 1; }
     m_flag += flag;
@@ -483,6 +501,7 @@ static void model_setup(const rt_scene_desc *sc) {
         if (sc->spheres[i].radius < 100 && sc->spheres[i].radius > rmax_small) rmax_small = sc->spheres[i].radius;
     }
     g_rho = rmax_small * 1.001f;
+    g_sqrtk = sqrtf(g_dynk * 1.0009765625f) * 1.000001f; g_parb = g_sqrtk * 1.7320509f * rmax_small * 1.000001f; g_parc3 = g_sqrtk * 1.7320509f;
     snode *save = g_s; const int save_n = g_sn;
     g_m = malloc(sizeof(snode) * 2 * (n + 1)); g_s = g_m; g_sn = 0;
     if (n > 0) sah_build(ids, n);
@@ -590,8 +609,8 @@ int main(int argc, char **argv) {
                            (double)df_pairs / n_rays, (double)df_leaf / n_rays, df_mismatch);
     if (g_leafk_on) printf("LEAFK=%d: pair steps/ray %.2f (bottom pairs %.2f)  leaf visits/ray %.2f  discriminants/ray %.2f  reaching roots/ray %.2f  mismatches (unguarded) %llu\n", g_leafk,
                            (double)k_pairs / n_rays, (double)k_bottom / n_rays, (double)k_visits / n_rays, (double)k_disc / n_rays, (double)k_roots / n_rays, k_mismatch);
-    if (g_model_on) printf("MODEL: pair steps/ray %.2f  leaf tests/ray %.2f (+ %.2f before the walk)  pops/ray %.2f  flagged %.4f%%  mismatches %llu (unflagged %llu)\n", (double)m_pairs / n_rays,
-                           (double)m_leaf / n_rays, (double)m_top / n_rays, (double)m_pops / n_rays, 100.0 * m_flag / n_rays, m_mismatch, m_mismatch_unflagged);
+    if (g_model_on) printf("MODEL: pair steps/ray %.2f  leaf tests/ray %.2f (+ %.2f before the walk)  pops/ray %.2f  flagged %.4f%%  mismatches %llu (unflagged %llu)  growth bound checked on %llu hits, broken %llu\n", (double)m_pairs / n_rays,
+                           (double)m_leaf / n_rays, (double)m_top / n_rays, (double)m_pops / n_rays, 100.0 * m_flag / n_rays, m_mismatch, m_mismatch_unflagged, m_inv_checked, m_inv_broken);
     printf("  max pending-stack depth per ray:");
     for (int i = 0; i < 24; i++) if (depth_hist[i]) printf(" %d:%.4f%%", i, 100.0 * depth_hist[i] / n_rays);
     printf("\n");
