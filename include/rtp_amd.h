@@ -214,9 +214,11 @@ typedef struct rt_config {
     int32_t  reserve_taper;       /* 1 (default): reservations shrink towards the end of a pass */
     int32_t  wavefront_paths;     /* RT_KERNEL_WAVEFRONT: paths in flight per wave, >= 128 (0 = auto) */
     int32_t  wavefront_exchange;  /* … lanes that must be free before a wave exchanges results for new rays (0 = auto) */
-    int32_t  wide_nodes;          /* developer build only (RT_ERR_UNSUPPORTED in the shipped library): 1 = the guarded walk uses the 4-wide form
-                                     of its tree — half the steps, but measured 6 % (S-rtiow) to 34 % (S-100k) slower on MI355X than the pair
-                                     walks: the walk is bound by its vector instructions, not by its round trips; 0 (default): child-pair nodes */
+    int32_t  wide_nodes;          /* 0 (default): scenes with distance-aware margins (guard_dynamic_margins) walk the 4-wide form of their tree —
+                                     half the dependent record loads per ray, and with the growth of the boxes in parametric form fewer
+                                     instructions as well (BASELINE configs[4] +1.7 %) —, every other scene child-pair nodes; -1: pair nodes
+                                     always; 1: 4-wide nodes for every guarded walk — developer build only (RT_ERR_UNSUPPORTED in the
+                                     shipped library): 6 % slower than the octant pair walk on S-rtiow */
     int32_t  guard_dynamic_margins; /* (fixed at create) margins of the guarded walk's small spheres: 0 = auto (distance-aware
                                      where one margin per sphere would exceed a quarter of the smallest radius), 1 = always one
                                      margin per sphere, 2 = always distance-aware */

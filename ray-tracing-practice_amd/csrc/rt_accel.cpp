@@ -739,7 +739,7 @@ void Packer::pair_tables() {
     // about the guarded walk holds unchanged.  Nodes are numbered breadth-first (top of the tree first, for the LDS
     // treelet of big scenes).
     //   wnodes  (fp32, 7 x float4): lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] code[4]
-    //   whnodes (binary16 rounded outward, 4 x float4): 24 halves in the same order, then code[4]
+    //   whnodes (binary16 rounded outward, 4 x float4): per axis the (lo, hi) pairs of the four children — one dword each: x[4] y[4] z[4] —, then code[4]
     //   unused child slots: code kTraversalDone (the kernel tells them by the code, not by the box).
     if (mode == TreeMode::Guarded && out.root >= 0) {
         struct Wide { int32_t child[4]; int n; };
@@ -784,8 +784,8 @@ void Packer::pair_tables() {
                 for (int a = 0; a < 3; ++a) {
                     o[(2 * a) * 4 + k] = b[2 * a];
                     o[(2 * a + 1) * 4 + k] = b[2 * a + 1];
-                    h[(2 * a) * 4 + k] = float_to_half_dir(b[2 * a], true);
-                    h[(2 * a + 1) * 4 + k] = float_to_half_dir(b[2 * a + 1], false);
+                    h[a * 8 + 2 * k] = float_to_half_dir(b[2 * a], true);            // per axis: the (lo, hi) pairs of the four children
+                    h[a * 8 + 2 * k + 1] = float_to_half_dir(b[2 * a + 1], false);
                 }
                 const int32_t mapped = code >= 0 ? wide_of[static_cast<size_t>(code)] : code;
                 o[24 + k] = bits_as_float(mapped);

@@ -127,8 +127,8 @@ rtaccel::PackOptions pack_options(const rt_config &cfg) {
     o.dynamic = cfg.guard_dynamic_margins;
     if (cfg.guard_gamma_ulps > 0.0f) o.gamma = (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8;
     o.leaf_table = cfg.guard_exact_leaf_table != 0;
-    // (the developer build's experimental kernels — wavefront, queue, 4-wide nodes — arm their rays themselves: everything stays in the tree)
-    o.front_max = (cfg.guard_front_primitives < 0 || cfg.kernel == RT_KERNEL_WAVEFRONT || cfg.wide_nodes != 0) ? 0 : rtaccel::kMaxFront;
+    // (the developer build's wavefront kernel arms its rays itself: everything stays in the tree)
+    o.front_max = (cfg.guard_front_primitives < 0 || cfg.kernel == RT_KERNEL_WAVEFRONT) ? 0 : rtaccel::kMaxFront;
     return o;
 }
 uint32_t bail_share_of(const rt_config &cfg) {      // in 1/256ths; 0 = never
@@ -351,9 +351,12 @@ rt_status fill_params(const rt_scene *sc, const rt_camera_data *cam, const rt_sh
     P.g_fark = sc->guard.far_k;
     P.g_dynk = sc->guard.dyn_k;
     {   // step_pair_par: sqrt(k) with the walk's slack, and sqrt(k) sqrt(3) r_max — both rounded up
-        const double sk = std::sqrt((double)sc->guard.dyn_k * (double)rtk::kDynSlack) * (1.0 + 1e-6);
+        // (sqrt(k) also multiplies the kernel's APPROXIMATE sqrt of |d|^2 — one ulp — and rounds in a float product: 4e-6 on top)
+        const double sk = std::sqrt((double)sc->guard.dyn_k * (double)rtk::kDynSlack) * (1.0 + 4e-6);
         P.g_dyn_sqrtk = std::nextafterf((float)sk, INFINITY);
         P.g_dyn_b = std::nextafterf((float)(sk * 1.7320508075688772 * (double)sc->guard.dyn_rmax * (1.0 + 1e-6)), INFINITY);
+        P.g_dyn_c3 = std::nextafterf((float)(sk * 1.7320508075688772), INFINITY);
+        P.g_dyn_kslack = std::nextafterf((float)((double)sc->guard.dyn_k * (double)rtk::kDynSlack), INFINITY);
     }
     P.num_front = sc->guard.num_front;
     std::memcpy(P.front_code, sc->guard.front_code, sizeof(P.front_code));
@@ -815,15 +818,18 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
 #ifndef RTP_DEV_BUILD
     if (want_wavefront) return fail(RT_ERR_UNSUPPORTED, "RT_KERNEL_WAVEFRONT is an experiment of the developer build (make dev): not in this library");
 #endif
-    // 4-wide nodes (developer build only: measured 6 % slower on S-rtiow and 34 % slower on S-100k than the pair walks as they are
-    // now — docs/LOG.md) where the scene has them (host-built tree with at least one inner node); the wavefront kernel walks pairs
+    // 4-wide nodes (where the scene has them: a host-built tree with at least one inner node).  Scenes with distance-aware margins
+    // walk them by default (step_wide_par: half the dependent record loads of the pair walk and, with the growth in parametric
+    // form, fewer instructions per ray — configs[4] +1.7 %).  For every other walk they stay an experiment of the developer build
+    // (rt_config.wide_nodes = 1: measured 6 % slower on S-rtiow; docs/LOG.md); the wavefront kernel walks pairs
 #ifndef RTP_DEV_BUILD
-    if (cfg.wide_nodes != 0) return fail(RT_ERR_UNSUPPORTED, "rt_config.wide_nodes is an experiment of the developer build (make dev): not in this library");
+    if (cfg.wide_nodes > 0) return fail(RT_ERR_UNSUPPORTED, "rt_config.wide_nodes = 1 is an experiment of the developer build (make dev): not in this library");
 #endif
-    // (those two arm their rays themselves: a tree without its front primitives — rt_accel.h — is not theirs to walk)
-    if ((want_wavefront || cfg.wide_nodes != 0) && sc->guard.num_front > 0)
-        return fail(RT_ERR_UNSUPPORTED, "the wavefront kernel and 4-wide nodes need a scene handle created with them selected (its tree must hold every primitive)");
-    const bool wide = sc->wnodes != nullptr && sc->num_wide > 0 && cfg.wide_nodes != 0 && !want_wavefront;
+    // (it arms its rays itself: a tree without its front primitives — rt_accel.h — is not its to walk)
+    if (want_wavefront && sc->guard.num_front > 0)
+        return fail(RT_ERR_UNSUPPORTED, "the wavefront kernel needs a scene handle created with it selected (its tree must hold every primitive)");
+    const bool wide_par_scene = sc->guard.dyn_k > 0.0f && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
+    const bool wide = sc->whnodes != nullptr && sc->num_wide > 0 && !want_wavefront && (cfg.wide_nodes > 0 || (cfg.wide_nodes == 0 && wide_par_scene));
     uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
     int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
     // the sphere-only build of the octant walk (render_kernel<…, kSimple>): 1024-thread workgroups, 8 waves per SIMD
@@ -890,7 +896,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // full stack, two workgroups per CU whatever the size of the tree).  The LDS-resident form of that walk lost on every
         // random scene it was tried on — tables of a thousand nodes leave room for one workgroup per CU or for a stack of four,
         // and the rays a short stack hands to the exact walk cost more than L1 does: tools/dyn_probe.py, docs/LOG.md round 4.
-        const bool dyn_global = sc->guard.dyn_k > 0.0f && !wide && !want_wavefront && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
+        const bool dyn_global = sc->guard.dyn_k > 0.0f && !want_wavefront && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
         fast.in_lds = cfg.scene_in_lds != 0 && !dyn_global;
         if (fast.in_lds) {
             fast.stack_levels = levels_for(table_bytes, fast.wgs_per_cu);
@@ -899,7 +905,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         }
         // (step_pair_dyn / step_pair_par, the walk of big scenes with distance-aware margins, keep a sentinel in level 0 — one level
         // more for the same twelve entries — and step_pair_par two rows of per-ray values behind the stack)
-        const bool dyn_pair = !fast.in_lds && sc->guard.dyn_k > 0.0f && !wide && !want_wavefront && RTP_DYN_ROTATE != 0;
+        const bool dyn_pair = !fast.in_lds && sc->guard.dyn_k > 0.0f && !want_wavefront && RTP_DYN_ROTATE != 0;       // (pair nodes, or their 4-wide form: step_wide_par)
         const int32_t extra_rows = dyn_pair ? (RTP_DYN_PARAM != 0 ? 2 : 0) : 0;
         if (!fast.in_lds) {
             // tables through L1/L2: a 12-entry stack per lane (deeper ones are rare enough to flag), the rest of
@@ -907,13 +913,14 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             fast.wgs_per_cu = gwgs_per_cu;
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const int64_t fit = budget > pool_bytes ? (int64_t)((budget - pool_bytes) / per_level) : 0;
-            const int32_t cap = (dyn_pair ? 13 : 12) + extra_rows;
+            // (the 4-wide walk leaves up to three children of a node waiting, and LDS holds nothing but the stacks: twenty entries)
+            const int32_t cap = (dyn_pair ? (wide ? 21 : 13) : 12) + extra_rows;
             fast.stack_levels = (int32_t)std::min<int64_t>(std::min<int64_t>(fit, want + extra_rows), cap);
         }
         if (const int forced = cfg.stack_levels) fast.stack_levels = forced + extra_rows < fast.stack_levels ? forced + extra_rows : fast.stack_levels;
         if (fast.stack_levels - extra_rows < (want < 2 ? want : 2)) guarded = false;
         // (step_pair_par reads every record through L1 / L2: RTP_DYN_TOP)
-        if (!fast.in_lds && cfg.lds_treelet && !(dyn_pair && RTP_DYN_PARAM != 0 && RTP_DYN_TOP == 0)) {
+        if (!fast.in_lds && cfg.lds_treelet && !(dyn_pair && RTP_DYN_PARAM != 0 && (RTP_DYN_TOP == 0 || wide))) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);
             const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;
@@ -1060,7 +1067,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     // with static margins, and the walk with distance-aware margins (LDS-resident or through L1/L2) — and a camera inside the
     // distance static margins were sized for (so that the far-origin test can never fire for a camera ray; the device compares
     // in float: a hair of slack)
-    bool prim = guarded && !wavefront && !use_queue && !wide && (dyn || ((RTP_OCTANT != 0) && fast.in_lds)) && cfg.primary_visibility >= 0 &&
+    bool prim = guarded && !wavefront && !use_queue && (!wide || (dyn && !fast.in_lds)) && (dyn || ((RTP_OCTANT != 0) && fast.in_lds)) && cfg.primary_visibility >= 0 &&
                 sc->nodes != nullptr && P.max_depth < rtk::kMaxPrimDepth;
     if (prim && sc->guard.num_small > 0) {
         const double dx = (double)cam->origin.e[0] - sc->guard.center[0], dy = (double)cam->origin.e[1] - sc->guard.center[1], dz = (double)cam->origin.e[2] - sc->guard.center[2];
@@ -1262,7 +1269,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             if (octant_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
             // big scene with distance-aware margins (tables through L1/L2, step_pair_dyn): a block of pair steps costs memory round
             // trips on top of its instructions — worth starting only for a nearly full wave (S-100k, swept 16-52 x 44-56: +4 %)
-            const bool big_dyn_launch = dyn && !fast.in_lds && !wide && !wavefront;
+            const bool big_dyn_launch = dyn && !fast.in_lds && !wavefront;
             if (big_dyn_launch && sc->cfg.k_inner <= 0) P.k_inner = 48;
             if (big_dyn_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
             P.flag_list = sc->flag_list;
@@ -1288,12 +1295,13 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
 #else
                 (void)launch_wf;
 #endif
+            } else if (wide && dyn && !fast.in_lds) {      // distance-aware margins on 4-wide nodes (step_wide_par)
+                if (prim) HIP_TRY(launch(rtk::render_kernel<false, false, true, true, false, true>, P, wgs, fast.lds_bytes));
+                else HIP_TRY(launch(rtk::render_kernel<false, false, true, true>, P, wgs, fast.lds_bytes));
             } else if (wide) {
 #ifdef RTP_DEV_BUILD
-                if (dyn) {
-                    if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, true, true>, P, wgs, fast.lds_bytes));
-                    else HIP_TRY(launch(rtk::render_kernel<false, false, true, true>, P, wgs, fast.lds_bytes));
-                } else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
+                if (dyn) HIP_TRY(launch(rtk::render_kernel<true, false, true, true>, P, wgs, fast.lds_bytes));
+                else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, false, true>, P, wgs, fast.lds_bytes));
 #endif
             } else if (dyn && fast.in_lds) {       // (only with RTP_DYN_PARAM or RTP_DYN_ROTATE off: developer variants)
