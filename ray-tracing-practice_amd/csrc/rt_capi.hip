@@ -828,8 +828,13 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     // (it arms its rays itself: a tree without its front primitives — rt_accel.h — is not its to walk)
     if (want_wavefront && sc->guard.num_front > 0)
         return fail(RT_ERR_UNSUPPORTED, "the wavefront kernel needs a scene handle created with it selected (its tree must hold every primitive)");
-    const bool wide_par_scene = sc->guard.dyn_k > 0.0f && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
-    const bool wide = sc->whnodes != nullptr && sc->num_wide > 0 && !want_wavefront && (cfg.wide_nodes > 0 || (cfg.wide_nodes == 0 && wide_par_scene));
+    // (a function of the handle's tables: evaluated again after a re-pack for a far camera — which may turn distance-aware margins
+    // on or off — below)
+    auto wide_nodes_wanted = [&]() {
+        const bool wide_par_scene = sc->guard.dyn_k > 0.0f && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
+        return sc->whnodes != nullptr && sc->num_wide > 0 && !want_wavefront && (cfg.wide_nodes > 0 || (cfg.wide_nodes == 0 && wide_par_scene));
+    };
+    bool wide = wide_nodes_wanted();
     uint32_t gblock = want_wavefront ? (uint32_t)rtk::kWfBlock : (uint32_t)rtk::kBlock;     // threads per workgroup of the guarded pass
     int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
     // the sphere-only build of the octant walk (render_kernel<…, kSimple>): 1024-thread workgroups, 8 waves per SIMD
@@ -852,6 +857,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             st = fill_params(sc, cam, shard, P, tile);       // table pointers and guard parameters changed
             if (st != RT_OK) return st;
             P.fb = d_fb_sum;
+            wide = wide_nodes_wanted();
         }
         if (outside(sc->guard.origin_center, (double)sc->guard.origin_radius * sc->guard.origin_radius)) guarded = false;
         if (sc->repack_refused && sc->guard.num_small > 0 && outside(sc->guard.center, (double)sc->guard.d0_sq)) guarded = false;
@@ -1298,8 +1304,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             } else if (wide && dyn && !fast.in_lds) {      // distance-aware margins on 4-wide nodes (step_wide_par)
                 if (prim) HIP_TRY(launch(rtk::render_kernel<false, false, true, true, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true, true>, P, wgs, fast.lds_bytes));
-            } else if (wide) {
 #ifdef RTP_DEV_BUILD
+            } else if (wide) {
                 if (dyn) HIP_TRY(launch(rtk::render_kernel<true, false, true, true>, P, wgs, fast.lds_bytes));
                 else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, false, true>, P, wgs, fast.lds_bytes));

@@ -770,6 +770,24 @@ def test_sphere_only_kernel_and_general_kernel_give_the_same_frame():
     assert t3.sphere_only == 0
 
 
+def test_first_frame_after_a_repack_that_changes_the_margins():
+    """A camera outside the reach the guarded walk's margins were sized for makes the handle re-pack its tree on the FIRST frame —
+    and the re-packed tree may have static margins where the first one had distance-aware ones (or the other way round): the walk,
+    its node form (pair / 4-wide) and the kernel are chosen from the tables as they are AFTER the re-pack.  (Round 4: a handle that
+    had picked 4-wide nodes for margins the re-pack then dropped launched nothing — found by tools/guard_stress.py, seed 1 scene 19.)"""
+    for seed, trial, n_want in ((1, 19, 118), (2, 39, 109), (7, 7, 2685)):
+        host, cam, n = _stress_scene(seed, trial, 12, 640, 360)
+        assert n == n_want
+        want, _ = rb.DeviceScene(host, device=0, honour_env=False, traversal=rb.TRAVERSAL_EXACT).render_to_host(cam)
+        assert_same_frame(want[180:182], ob.render(host, cam, row0=180, row1=182, threads=8), "exact walk against the oracle")
+        for kw in (dict(traversal=rb.TRAVERSAL_AUTO, guard_keep=0), dict(traversal=rb.TRAVERSAL_GUARDED, guard_keep=1)):
+            dev = rb.DeviceScene(host, device=0, honour_env=False, **kw)
+            for frame in range(3):
+                fb, t = dev.render_to_host(cam)
+                assert_same_frame(fb, want, f"seed {seed} scene {trial}, frame {frame}, {kw}")
+                assert t.trace_ms > 0.05, "a trace launch that did nothing"
+
+
 def test_candidate_lists_are_reused_for_the_same_view(rtiow):
     """The per-pixel candidate lists and the fetch order are kept with the handle: a call with the same camera, image, shard and
     tree on the same stream (the next batch of a progressive render) does not make them again, any other call does — frames are the
