@@ -365,7 +365,9 @@ def worker(args):
 
     host = make_host_scene()
     cam = rb.rtiow_camera(WIDTH, HEIGHT, args.spp, DEPTH)
-    dev = rb.DeviceScene(host)                      # scene resident in HBM before timing
+    # scene resident in HBM before timing.  reuse_view_lists = -1: every timed frame makes its per-pixel candidate lists itself —
+    # the library's default keeps them for a repeated view, and a benchmark step is ALL of a frame's work
+    dev = rb.DeviceScene(host, reuse_view_lists=-1)
     band = fp.DEFAULT_BAND_ROWS
     shard = fp.shard_for_rank(rank, world, band) if world > 1 else None
     local_rows = rb.amd_lib().rt_shard_rows(HEIGHT, C.byref(shard) if shard else None)
@@ -455,7 +457,10 @@ def worker(args):
                        "world_size_seen_by_collective": (dist.get_world_size() if world > 1 else 1),
                        "traversal": ("guarded near-first walk + exact re-walk of flagged samples" if guarded and guarded[0]
                                      else "reference-order (threaded) walk"),
-                       "primary_visibility": bool(last_t[0] is not None and last_t[0].primary_visibility)},
+                       "primary_visibility": bool(last_t[0] is not None and last_t[0].primary_visibility),
+                       "front_primitives": int(last_t[0].front_primitives) if last_t[0] is not None else 0,
+                       "wide_nodes": bool(last_t[0] is not None and last_t[0].wide_nodes),
+                       "view_lists_reused_between_steps": False},
         }
         base, st = (None, None)
         if world > 1 and os.environ.get("RTP_BENCH_CHECK"):

@@ -246,6 +246,10 @@ typedef struct rt_config {
                                      walk's tree; every ray tests them when it is armed, all lanes of a wave together, and walks with their
                                      hit as its closest so far (the same frame bit for bit: the guarded walk's result does not depend on
                                      the order of its tests); -1: every primitive is a leaf of the tree */
+    int32_t  reuse_view_lists;    /* 0 (default): the per-pixel candidate lists of the primary-visibility pass and the fetch order made from
+                                     them are kept with the handle, and a call with the same camera, image, shard and tree on the same
+                                     stream (the next batch of a progressive render, the next frame of a still) does not make them again
+                                     (0.4 ms at 1920x1080); -1: every call makes them (bench.py: every timed frame does all of a frame's work) */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */

@@ -107,6 +107,7 @@ void config_defaults(rt_config &c) {
     c.wide_nodes = 0;
     c.guard_bail_share = 0;
     c.guard_front_primitives = 0;
+    c.reuse_view_lists = 0;
 }
 
 // A caller compiled against an older, shorter rt_config: its fields, defaults for the rest.
@@ -496,6 +497,7 @@ void rt_config_from_env(rt_config *user) {
     if (env_int("RTP_NO_PRIMARY", 0)) cfg->primary_visibility = -1;
     cfg->guard_bail_share = env_int("RTP_BAIL_SHARE", cfg->guard_bail_share);
     if (env_int("RTP_NO_FRONT", 0)) cfg->guard_front_primitives = -1;
+    if (env_int("RTP_NO_VIEW_CACHE", 0)) cfg->reuse_view_lists = -1;
     const uint32_t n = user->struct_bytes < sizeof(rt_config) ? user->struct_bytes : (uint32_t)sizeof(rt_config);
     std::memcpy(user, &full, n);
     user->struct_bytes = n;
@@ -1111,7 +1113,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         std::memcpy(key.dims, dims, sizeof(dims));
         key.repacks = sc->repacks; key.stream = stream; key.valid = true;
     }
-    const bool cand_cached = prim && sc->cand_key.valid && std::memcmp(key.view, sc->cand_key.view, sizeof(key.view)) == 0 &&
+    const bool cand_cached = prim && cfg.reuse_view_lists >= 0 && sc->cand_key.valid && std::memcmp(key.view, sc->cand_key.view, sizeof(key.view)) == 0 &&
                              std::memcmp(key.dims, sc->cand_key.dims, sizeof(key.dims)) == 0 && key.repacks == sc->cand_key.repacks && key.stream == sc->cand_key.stream;
     if (!cand_cached) sc->cand_key.valid = false;          // (valid again once the launches below are queued)
     if (prim && !cand_cached) {

@@ -88,7 +88,7 @@ class Config(C.Structure):
                 ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
                 ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32),
                 ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32), ("primary_visibility", C.c_int32),
-                ("guard_bail_share", C.c_int32), ("guard_front_primitives", C.c_int32)]
+                ("guard_bail_share", C.c_int32), ("guard_front_primitives", C.c_int32), ("reuse_view_lists", C.c_int32)]
 
 
 def new_config():
