@@ -529,7 +529,13 @@ void Packer::prepare_guard() {
                 double r_max_small = 0;
                 for (int i = 0; i < d.num_spheres; ++i)
                     if (leaf_of_sphere[static_cast<size_t>(i)] >= 0 && !large[static_cast<size_t>(i)]) r_max_small = std::max(r_max_small, double(d.spheres[i].radius));
-                const bool dynamic = opt.dynamic == 2 || (opt.dynamic == 0 && eps_static > 0.25 * r_min_small && r_max_small <= 8.0 * r_min_small);
+                // … and where the tree is too big for the LDS-resident walk anyway and the static margins are small: the growth is
+                // smaller than they are everywhere within reach, and the walk through L1 / L2 (step_wide_par) does not care how big the
+                // tree is (S-rtiow scaled to 785 / 1 298 spheres: 6.8 / 5.2 Gsamples/s LDS-resident at one workgroup per CU, ≈ 7.5
+                // through L1 / L2; tools/size_sweep.py)
+                const bool too_big_for_lds = opt.lds_pair_budget > 0 && static_cast<int64_t>(leaves.size()) - 1 > opt.lds_pair_budget;
+                const bool dynamic = opt.dynamic == 2 || (opt.dynamic == 0 && ((eps_static > 0.25 * r_min_small && r_max_small <= 8.0 * r_min_small) ||
+                                                                               (too_big_for_lds && eps_static <= 0.25 * r_min_small)));
                 if (!dynamic && eps_static > 64.0 * r_min_small) why = "margins exceed 64 radii for the smallest spheres";
                 const double d0 = reach - rs;
                 for (int i = 0; i < d.num_spheres; ++i)

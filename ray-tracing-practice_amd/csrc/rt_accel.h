@@ -112,6 +112,10 @@ struct PackOptions {
     int dynamic = 0;                   // distance-aware margins for the small spheres: 0 = where static ones would exceed a
                                        // quarter of the smallest radius, 1 = never, 2 = always
     int front_max = kMaxFront;         // at most this many front primitives (Packed::Guard::num_front); 0: every primitive is a leaf of the tree
+    int lds_pair_budget = 0;           // > 0: how many pair nodes the LDS-resident walk can hold at full occupancy.  A scene with more, whose
+                                       // static margins would be small (under a quarter of the smallest radius: the distance-aware growth is
+                                       // smaller still), gets distance-aware margins and with them the walk through L1 / L2 — instead of an
+                                       // LDS-resident walk at one workgroup per CU or with a stack of four (dynamic == 0 only)
 };
 
 // binary16 helpers of the half-precision node table (exposed for the native test)

@@ -123,8 +123,23 @@ rt_config config_from_caller(const rt_config *in) {
     return c;
 }
 
-rtaccel::PackOptions pack_options(const rt_config &cfg) {
+// Pair nodes the LDS-resident guarded walk can hold at two workgroups per CU with a stack of seven entries (what render_impl's own
+// fit test comes to for the sphere-only build and the general one) — PackOptions::lds_pair_budget: scenes beyond it are packed for
+// the walk through L1 / L2 where that costs nothing.  An estimate is enough: both walks render the same frame.
+int32_t lds_pair_budget(const rt_scene_desc &d) {
+    bool plain = d.num_planes == 0;          // the sphere-only build: no planes, no textures (absorbing glass aside: the estimate may be a little generous)
+    for (int i = 0; plain && i < d.num_materials; ++i) plain = d.materials[i].texture_id == 0;
+    const int64_t budget = (int64_t)kLdsLimit / 2;
+    const int64_t lanes = plain ? rtk::kSimpleBlock : rtk::kBlock;
+    const int64_t fixed = (int64_t)d.num_spheres * 16 + ((int64_t)d.num_spheres + 3) / 4 * 16 + (int64_t)d.num_planes * 80 +
+                          (plain ? 0 : (int64_t)d.num_materials * 16 * RTP_LDS_MAT_ROWS) + 16 * rtk::kConstRows + (lanes / 64) * (8 + 32 * 4) + 7 * lanes * 4;
+    const int64_t nodes = (budget - fixed) / rtk::kOctNodeBytes;
+    return (int32_t)(nodes < 1 ? 1 : nodes);
+}
+
+rtaccel::PackOptions pack_options(const rt_config &cfg, const rt_scene_desc *d = nullptr) {
     rtaccel::PackOptions o;
+    if (d && cfg.scene_in_lds != 0) o.lds_pair_budget = lds_pair_budget(*d);
     o.dynamic = cfg.guard_dynamic_margins;
     if (cfg.guard_gamma_ulps > 0.0f) o.gamma = (double)cfg.guard_gamma_ulps * 5.9604644775390625e-8;
     o.leaf_table = cfg.guard_exact_leaf_table != 0;
@@ -385,7 +400,7 @@ rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream
     d.planes = planes.data();
     d.materials = &dummy; d.num_materials = 1;
     rtaccel::Packed pk;
-    const std::string err = rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk, pack_options(sc->cfg), cam);
+    const std::string err = rtaccel::pack_scene(d, rtaccel::TreeMode::Guarded, pk, pack_options(sc->cfg, &d), cam);
     if (!err.empty()) return fail(RT_ERR_INVALID_ARG, "re-pack for a far camera: " + err);
     if (!pk.guard.ok) {          // margins for that distance would swallow the tree: such cameras get the exact walk
         sc->repack_refused = true;
@@ -533,7 +548,7 @@ rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cf
     const rt_config cfg = config_from_caller(user_cfg);
     if (cfg.guard_gamma_ulps < 0.0f || !(cfg.guard_gamma_ulps == cfg.guard_gamma_ulps)) return fail(RT_ERR_INVALID_ARG, "guard_gamma_ulps must be >= 0");
     rtaccel::Packed pk;
-    const rtaccel::PackOptions popt = pack_options(cfg);
+    const rtaccel::PackOptions popt = pack_options(cfg, desc);
     // RT_BUILD_DEVICE_LBVH: the guarded walk's tree is built on the GPU (LBVH, rt_build.hip) instead of the host's SAH
     // builder — any tree over the inflated leaves gives the same image (docs/LOG.md §3b)
     const bool device_build = cfg.tree_build == RT_BUILD_DEVICE_LBVH;
