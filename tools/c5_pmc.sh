@@ -4,7 +4,7 @@
 set -eo pipefail
 SPP=${1:-64}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/c5_pmc_r03
+OUT=$ROOT/gpurun_out/c5_pmc_r04
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp SPP
 RUN="python3 $ROOT/tools/c5_run.py"
@@ -20,7 +20,7 @@ for f in glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True
         if 'render_kernel<false, false' in r['Kernel_Name']:
             acc[r['Counter_Name']] += float(r['Counter_Value']); cnt[r['Counter_Name']] += 1
 m = {k: acc[k] / cnt[k] for k in acc}
-out = {'kernel': 'rtk::render_kernel<false, false, true, false, false, true> (guarded walk fed by the primary-visibility pass, distance-aware margins, tables through L1/L2)', 'launches': cnt.get('SQ_INSTS_VALU', 0), 'per_launch_mean': m}
+out = {'kernel': 'rtk::render_kernel<false, false, true, true, false, true> (guarded walk on 4-wide nodes fed by the primary-visibility pass, distance-aware margins in parametric form, records through L1/L2)', 'launches': cnt.get('SQ_INSTS_VALU', 0), 'per_launch_mean': m}
 if 'GRBM_GUI_ACTIVE' in m:
     cycles = m['GRBM_GUI_ACTIVE'] / 8
     out['valu_issue_utilisation'] = round(2 * m['SQ_INSTS_VALU'] / (1024 * cycles), 4)
