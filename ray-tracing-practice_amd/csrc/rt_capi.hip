@@ -453,7 +453,7 @@ const char *rt_get_last_error_string(void) { return g_last_error.c_str(); }
 #else
 #define RTP_VERSION_DEV "0"
 #endif
-const char *rt_version_string(void) { return "rtp_amd 0.3 gfx950 parity=" RTP_VERSION_PARITY " dev=" RTP_VERSION_DEV; }
+const char *rt_version_string(void) { return "rtp_amd 0.4 gfx950 parity=" RTP_VERSION_PARITY " dev=" RTP_VERSION_DEV; }
 
 rt_status rt_set_device(int32_t device_ordinal) {
     int n = 0;
