@@ -788,6 +788,29 @@ def test_first_frame_after_a_repack_that_changes_the_margins():
                 assert t.trace_ms > 0.05, "a trace launch that did nothing"
 
 
+def test_scene_sizes_around_what_lds_holds():
+    """The S-rtiow family across the size at which its tables stop fitting LDS at full occupancy: up to there the sphere-only
+    octant walk, beyond it distance-aware margins (small where static ones would have done) and the walk on 4-wide nodes through
+    L1 / L2 — chosen at pack time (PackOptions::lds_pair_budget), reported in rt_timing; frames are the oracle's on both sides, and
+    with the rule switched off (guard_dynamic_margins = 1: one margin per sphere, LDS-resident whatever the occupancy)."""
+    seen = set()
+    for half in (11, 12, 13, 16):
+        host = rb.HostScene.rtiow(half_extent=half)
+        cam = rb.rtiow_camera(160, 90, 10, 50)
+        want = ob.render(host, cam, threads=8)
+        dev = rb.DeviceScene(host, device=0, honour_env=False)
+        fb, t = dev.render_to_host(cam)
+        assert t.guarded == 1 and t.front_primitives == 1 and t.primary_visibility == 1
+        assert (t.scene_in_lds, t.guard_dynamic, t.wide_nodes) in ((1, 0, 0), (0, 1, 1)), (half, t.scene_in_lds, t.guard_dynamic, t.wide_nodes)
+        seen.add(t.scene_in_lds)
+        assert_same_frame(fb, want, f"half_extent {half}: {host.desc.num_spheres} spheres")
+        static = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=1)
+        fb, t = static.render_to_host(cam)
+        assert t.guarded == 1 and t.guard_dynamic == 0 and t.scene_in_lds == 1
+        assert_same_frame(fb, want, f"half_extent {half}, static margins")
+    assert seen == {0, 1}, "both sides of the limit"
+
+
 def test_candidate_lists_are_reused_for_the_same_view(rtiow):
     """The per-pixel candidate lists and the fetch order are kept with the handle: a call with the same camera, image, shard and
     tree on the same stream (the next batch of a progressive render) does not make them again, any other call does — frames are the
