@@ -888,6 +888,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         const int32_t deepest = wide ? 3 * sc->wide_depth : sc->tree_depth;          // a wide node leaves up to three children waiting
         const int32_t want = deepest + 1 > 2 ? deepest + 1 : 2;       // never overflows
         uint32_t per_level = gblock * 4u;
+        uint32_t pool_extra = 0;       // (the sphere-only builds have four more waves' work ranges than pool_bytes counts)
         // sphere-only build: no planes, no textures, leaf boxes recomputed from the spheres; its LDS holds no material rows
         // (all three come from global memory), which pays for the wider stack rows of 1024 lanes
         simple = octant && cfg.scene_in_lds != 0 && cfg.sphere_only_kernel >= 0 && P.num_planes == 0 && sc->tex_data == nullptr &&
@@ -904,6 +905,19 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             } else {
                 simple = false;
             }
+        }
+        // … and of the walk through L1 / L2 for scenes with distance-aware margins (step_pair_par on pair nodes: the 4-wide step does
+        // not fit 64 registers): sphere-only scenes beyond what LDS holds — S-rtiow x 785 … 99 857 spheres: +7 … +10 % over the general
+        // build on 4-wide nodes (8.1 / 7.7 / 6.7 / 3.9 against 7.5 / 7.2 / 6.2 / 3.6 Gsamples/s; tools/size_sweep.py)
+        const bool dyn_global_scene = sc->guard.dyn_k > 0.0f && !want_wavefront && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0 && cfg.wide_nodes <= 0;
+        if (!simple && dyn_global_scene && cfg.sphere_only_kernel >= 0 && P.num_planes == 0 && sc->tex_data == nullptr && P.leaf_boxes == nullptr &&
+            cfg.workgroups_per_cu == 0 && !sc->absorbing_glass) {
+            simple = true;
+            wide = false;
+            gblock = (uint32_t)rtk::kSimpleBlock;
+            gwgs_per_cu = rtk::kSimpleWaves * 256 / rtk::kSimpleBlock;
+            per_level = gblock * 4u;
+            pool_extra = (uint32_t)(rtk::kSimpleBlock / rtk::kWave) * 8u - pool_bytes;
         }
         // tables in LDS when they leave room for a useful stack at full occupancy; else they are read
         // through L1/L2 and LDS holds only the stacks
@@ -935,7 +949,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             // the workgroup's LDS share holds the top of the tree
             fast.wgs_per_cu = gwgs_per_cu;
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
-            const int64_t fit = budget > pool_bytes ? (int64_t)((budget - pool_bytes) / per_level) : 0;
+            const int64_t fit = budget > pool_bytes + pool_extra + 16u * rtk::kConstRows ? (int64_t)((budget - pool_bytes - pool_extra - 16u * rtk::kConstRows) / per_level) : 0;
             // (the 4-wide walk leaves up to three children of a node waiting, and LDS holds nothing but the stacks: twenty entries)
             const int32_t cap = (dyn_pair ? (wide ? 21 : 13) : 12) + extra_rows;
             fast.stack_levels = (int32_t)std::min<int64_t>(std::min<int64_t>(fit, want + extra_rows), cap);
@@ -950,8 +964,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             const int32_t top_have = wide ? sc->num_top_wide : sc->num_top_pairs;
             fast.num_top = (int32_t)(fit < top_have ? fit : top_have);
         }
-        if (!fast.in_lds || fast.wgs_per_cu != gwgs_per_cu) simple = false;      // (cannot happen after the fit test above; the general kernel is always right)
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + (!want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
+        if ((!fast.in_lds && !dyn_global_scene) || fast.wgs_per_cu != gwgs_per_cu) simple = false;      // (cannot happen after the fit test above; the general kernel is always right)
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + pool_extra + (!want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
                                     (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
         // what is left of the workgroup's LDS share stages flagged samples per wave (render_kernel, flag_append): 32, 16 or 8 words
@@ -1330,6 +1344,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             } else if (dyn && fast.in_lds) {       // (only with RTP_DYN_PARAM or RTP_DYN_ROTATE off: developer variants)
                 if (prim) HIP_TRY(launch(rtk::render_kernel<true, false, true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
+            } else if (dyn && simple) {      // sphere-only scenes beyond what LDS holds: step_pair_par at 64 registers, 8 waves per SIMD
+                if (prim) HIP_TRY(launch_simple(rtk::render_kernel<false, false, true, false, true, true>, P, wgs, fast.lds_bytes));
+                else HIP_TRY(launch_simple(rtk::render_kernel<false, false, true, false, true>, P, wgs, fast.lds_bytes));
             } else if (dyn) {
                 if (prim) HIP_TRY(launch(rtk::render_kernel<false, false, true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true>, P, wgs, fast.lds_bytes));
@@ -1444,7 +1461,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     sc->last.guard_dynamic = dyn ? 1u : 0u;
     sc->last.front_primitives = guarded ? (uint32_t)sc->guard.num_front : 0u;
     sc->last.wide_nodes = (guarded && wide) ? 1u : 0u;
-    sc->last.sphere_only = ((guarded && simple && !wavefront && !wide && !dyn) || (!guarded && exact_simple)) ? 1u : 0u;
+    sc->last.sphere_only = ((guarded && simple && !wavefront && !wide) || (!guarded && exact_simple)) ? 1u : 0u;
     sc->last.primary_visibility = prim ? 1u : 0u;
     sc->last.trace_vgprs = trace_vgprs;
     sc->last.trace_scratch_bytes = trace_scratch;

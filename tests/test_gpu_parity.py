@@ -790,9 +790,10 @@ def test_first_frame_after_a_repack_that_changes_the_margins():
 
 def test_scene_sizes_around_what_lds_holds():
     """The S-rtiow family across the size at which its tables stop fitting LDS at full occupancy: up to there the sphere-only
-    octant walk, beyond it distance-aware margins (small where static ones would have done) and the walk on 4-wide nodes through
-    L1 / L2 — chosen at pack time (PackOptions::lds_pair_budget), reported in rt_timing; frames are the oracle's on both sides, and
-    with the rule switched off (guard_dynamic_margins = 1: one margin per sphere, LDS-resident whatever the occupancy)."""
+    octant walk, beyond it distance-aware margins (small where static ones would have done) and the walk through L1 / L2 — its
+    sphere-only build on pair nodes, or with sphere_only_kernel = -1 the general one on 4-wide nodes — chosen at pack time
+    (PackOptions::lds_pair_budget), reported in rt_timing; frames are the oracle's on both sides, and with the rule switched off
+    (guard_dynamic_margins = 1: one margin per sphere, LDS-resident whatever the occupancy)."""
     seen = set()
     for half in (11, 12, 13, 16):
         host = rb.HostScene.rtiow(half_extent=half)
@@ -801,9 +802,13 @@ def test_scene_sizes_around_what_lds_holds():
         dev = rb.DeviceScene(host, device=0, honour_env=False)
         fb, t = dev.render_to_host(cam)
         assert t.guarded == 1 and t.front_primitives == 1 and t.primary_visibility == 1
-        assert (t.scene_in_lds, t.guard_dynamic, t.wide_nodes) in ((1, 0, 0), (0, 1, 1)), (half, t.scene_in_lds, t.guard_dynamic, t.wide_nodes)
+        assert (t.scene_in_lds, t.guard_dynamic, t.wide_nodes, t.sphere_only) in ((1, 0, 0, 1), (0, 1, 0, 1)), (half, t.scene_in_lds, t.guard_dynamic, t.wide_nodes)
         seen.add(t.scene_in_lds)
         assert_same_frame(fb, want, f"half_extent {half}: {host.desc.num_spheres} spheres")
+        general = rb.DeviceScene(host, device=0, honour_env=False, sphere_only_kernel=-1)
+        fb, t = general.render_to_host(cam)
+        assert (t.guard_dynamic, t.wide_nodes, t.sphere_only) in ((0, 0, 0), (1, 1, 0)), (half, t.guard_dynamic, t.wide_nodes, t.sphere_only)
+        assert_same_frame(fb, want, f"half_extent {half}, general build")
         static = rb.DeviceScene(host, device=0, honour_env=False, guard_dynamic_margins=1)
         fb, t = static.render_to_host(cam)
         assert t.guarded == 1 and t.guard_dynamic == 0 and t.scene_in_lds == 1
