@@ -222,9 +222,10 @@ typedef struct rt_config {
     int32_t  guard_dynamic_margins; /* (fixed at create) margins of the guarded walk's small spheres: 0 = auto (distance-aware
                                      where one margin per sphere would exceed a quarter of the smallest radius), 1 = always one
                                      margin per sphere, 2 = always distance-aware */
-    int32_t  sphere_only_kernel;  /* 0 (default): scenes without planes, textures and absorbing dielectrics whose tables fit LDS are rendered by the
-                                     sphere-only build of the guarded kernel (64 registers per lane, 8 waves per SIMD instead of
-                                     6; the same frame bit for bit); -1: always the general kernel */
+    int32_t  sphere_only_kernel;  /* 0 (default): scenes without planes, textures and absorbing dielectrics are rendered by the sphere-only
+                                     build of the guarded kernel (64 registers per lane, 8 waves per SIMD instead of 6; the same frame bit
+                                     for bit) — the LDS-resident octant walk where the tables fit, the pair walk through L1 / L2 with
+                                     distance-aware margins beyond; -1: always the general kernel */
     int32_t  overlap_rework;      /* 0 (default): the exact re-walk of flagged samples and the accumulation of their pixels run on a
                                      second stream of the handle beside the accumulation of all other pixels; -1: one after the other */
     int32_t  primary_visibility;  /* 0 (default): where the guarded walk's tables are LDS-resident, the first hit of every camera ray
