@@ -17,6 +17,8 @@ def material(rng):
     m.type = int(rng.integers(0, 4)); m.fuzz = float(rng.uniform(0, 0.7)); m.ir = float(rng.uniform(1.1, 2.0))
     m.albedo.e[:] = rng.uniform(0.1, 1.0, 3)
     m.absorption.e[:] = rng.uniform(0, 0.6, 3) if rng.random() < 0.5 else (0, 0, 0)
+    if os.environ.get("NOABS"):          # no absorbing glass: scenes without planes take the sphere-only builds (the draw above stays: same scenes otherwise)
+        m.absorption.e[:] = (0, 0, 0)
     m.emit.e[:] = rng.uniform(0.5, 3.0, 3) if m.type == 3 else (0, 0, 0)
     m.texture_id = 0
     return m
