@@ -848,7 +848,10 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     // (a function of the handle's tables: evaluated again after a re-pack for a far camera — which may turn distance-aware margins
     // on or off — below)
     auto wide_nodes_wanted = [&]() {
-        const bool wide_par_scene = sc->guard.dyn_k > 0.0f && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
+        // (step_wide_par tells an empty child slot by its box — the finite inverted (65504, -65504) of the binary16 table — which holds
+        // while the growth stays below 65504: it never exceeds dyn_k x (twice the radius every ray origin lies within)^2)
+        const double growth_max = (double)sc->guard.dyn_k * 4.0 * (double)sc->guard.origin_radius * (double)sc->guard.origin_radius;
+        const bool wide_par_scene = sc->guard.dyn_k > 0.0f && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0 && growth_max < 16384.0;
         return sc->whnodes != nullptr && sc->num_wide > 0 && !want_wavefront && (cfg.wide_nodes > 0 || (cfg.wide_nodes == 0 && wide_par_scene));
     };
     bool wide = wide_nodes_wanted();
