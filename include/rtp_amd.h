@@ -251,6 +251,10 @@ typedef struct rt_config {
                                      them are kept with the handle, and a call with the same camera, image, shard and tree on the same
                                      stream (the next batch of a progressive render, the next frame of a still) does not make them again
                                      (0.4 ms at 1920x1080); -1: every call makes them (bench.py: every timed frame does all of a frame's work) */
+    int32_t  resume_flagged;      /* 0 (default): the exact re-walk of a sample the guarded walk flagged goes on from the ray that was flagged —
+                                     the path's state at that point is left in a 17 MB table of the handle (a sample whose slot is taken, or
+                                     that was flagged inside a shade step, is redone from its camera ray as before); -1: every flagged
+                                     sample is redone from the camera.  The same frame bit for bit: up to the flagged ray both walks agree */
 } rt_config;
 
 /* ---- entry points -------------------------------------------------------------------------- */

@@ -108,6 +108,7 @@ void config_defaults(rt_config &c) {
     c.guard_bail_share = 0;
     c.guard_front_primitives = 0;
     c.reuse_view_lists = 0;
+    c.resume_flagged = 0;
 }
 
 // A caller compiled against an older, shorter rt_config: its fields, defaults for the rest.
@@ -211,6 +212,9 @@ struct rt_scene {
     int32_t last_spp = 0;
     float4 *leaf_boxes = nullptr, *plane_leaf_boxes = nullptr;   // exact leaf boxes (final check of the guarded walk)
     uint32_t *flag_list = nullptr;  // work indices of flagged samples, grown on demand
+    // resume table (rt_kernel.hip.inc): where a flagged sample's path stood when the flagged ray was armed — 2^18 tags + 64-byte states
+    // (17 MB), made with the first guarded frame; a device short of memory renders without it (flagged samples restart from the camera)
+    uint32_t *resume_tag = nullptr; float4 *resume_state = nullptr;
     size_t flag_cap = 0;
     // overlapped re-walk: the exact re-walk + the accumulation of the pixels it touches run on aux_stream beside the
     // accumulation of all other pixels on the caller's stream
@@ -513,6 +517,7 @@ void rt_config_from_env(rt_config *user) {
     cfg->guard_bail_share = env_int("RTP_BAIL_SHARE", cfg->guard_bail_share);
     if (env_int("RTP_NO_FRONT", 0)) cfg->guard_front_primitives = -1;
     if (env_int("RTP_NO_VIEW_CACHE", 0)) cfg->reuse_view_lists = -1;
+    if (env_int("RTP_NO_RESUME", 0)) cfg->resume_flagged = -1;
     const uint32_t n = user->struct_bytes < sizeof(rt_config) ? user->struct_bytes : (uint32_t)sizeof(rt_config);
     std::memcpy(user, &full, n);
     user->struct_bytes = n;
@@ -636,6 +641,7 @@ rt_status rt_scene_destroy(rt_scene *sc) {
     (void)hipFree(sc->sphere_mat); (void)hipFree(sc->tex_data); (void)hipFree(sc->tex_info); (void)hipFree(sc->queue); (void)hipFree(sc->slab);
     (void)hipFree(sc->leaf_boxes); (void)hipFree(sc->plane_leaf_boxes); (void)hipFree(sc->flag_list); (void)hipFree(sc->wf_pool);
     (void)hipFree(sc->dirty); (void)hipFree(sc->dirty_list); (void)hipFree(sc->cand);
+    (void)hipFree(sc->resume_tag); (void)hipFree(sc->resume_state);
     if (sc->aux_stream) (void)hipStreamDestroy(sc->aux_stream);
     if (sc->list_stream) (void)hipStreamDestroy(sc->list_stream);
     if (sc->ev_listed) (void)hipEventDestroy(sc->ev_listed);
@@ -1313,6 +1319,22 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             if (big_dyn_launch && sc->cfg.k_inner <= 0) P.k_inner = 48;
             if (big_dyn_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
             P.flag_list = sc->flag_list;
+            // resume table: cleared per pass (1 MB of tags); not for the experimental kernels, nor for paths longer than the depth field
+            constexpr uint32_t kResumeBits = 18;
+            if (!wavefront && cfg.resume_flagged >= 0 && P.max_depth < rtk::kMaxPrimDepth) {
+                if (sc->resume_tag == nullptr) {
+                    if (hipMalloc((void **)&sc->resume_tag, sizeof(uint32_t) << kResumeBits) != hipSuccess ||
+                        hipMalloc((void **)&sc->resume_state, (size_t)64 << kResumeBits) != hipSuccess) {
+                        (void)hipGetLastError();
+                        (void)hipFree(sc->resume_tag); (void)hipFree(sc->resume_state);
+                        sc->resume_tag = nullptr; sc->resume_state = nullptr;
+                    }
+                }
+                if (sc->resume_tag != nullptr) HIP_TRY(hipMemsetAsync(sc->resume_tag, 0, sizeof(uint32_t) << kResumeBits, stream));
+                P.resume_tag = sc->resume_tag; P.resume_state = sc->resume_state; P.resume_shift = 32u - kResumeBits;
+            } else {
+                P.resume_tag = nullptr; P.resume_state = nullptr;
+            }
             P.flag_count = sc->queue + kQueueFlag + pass;
             P.dirty = overlap ? sc->dirty : nullptr;
             if (overlap) HIP_TRY(hipMemsetAsync(sc->dirty, 0, (size_t)num_pixels * sizeof(uint32_t), stream));      // this pass's marks (8 MB at 1080p: microseconds)

@@ -88,7 +88,7 @@ class Config(C.Structure):
                 ("reserve_chunk", C.c_int32), ("reserve_taper", C.c_int32), ("wavefront_paths", C.c_int32),
                 ("wavefront_exchange", C.c_int32), ("wide_nodes", C.c_int32), ("guard_dynamic_margins", C.c_int32),
                 ("sphere_only_kernel", C.c_int32), ("overlap_rework", C.c_int32), ("primary_visibility", C.c_int32),
-                ("guard_bail_share", C.c_int32), ("guard_front_primitives", C.c_int32), ("reuse_view_lists", C.c_int32)]
+                ("guard_bail_share", C.c_int32), ("guard_front_primitives", C.c_int32), ("reuse_view_lists", C.c_int32), ("resume_flagged", C.c_int32)]
 
 
 def new_config():
@@ -97,7 +97,7 @@ def new_config():
     lib = amd_lib()
     if hasattr(lib, "rt_config_init_sized"):
         lib.rt_config_init_sized(C.byref(cfg), C.sizeof(Config))
-        assert cfg.struct_bytes == C.sizeof(Config), (cfg.struct_bytes, C.sizeof(Config))
+        assert cfg.struct_bytes == C.sizeof(Config) or os.environ.get("RTP_AMD_LIB"), (cfg.struct_bytes, C.sizeof(Config))
     else:       # an OLDER build loaded through RTP_AMD_LIB for an A/B run (developer tools): it fills the fields it has
         assert os.environ.get("RTP_AMD_LIB")
         lib.rt_config_init(C.byref(cfg))

@@ -816,6 +816,27 @@ def test_scene_sizes_around_what_lds_holds():
     assert seen == {0, 1}, "both sides of the limit"
 
 
+def test_flagged_samples_resume_from_the_flagged_ray(rtiow):
+    """rt_config.resume_flagged: the exact re-walk of a flagged sample goes on from the ray that was flagged (its path's state is left
+    in a table of the handle) instead of redoing the sample from the camera — the same frame, which is the oracle's: with the few
+    flags of the default walk, with a stack so short that a sixth of the samples is flagged at every depth of their paths (far
+    more than the table has slots: the others restart), over several passes, and with the primary-visibility pass off."""
+    host, _ = rtiow
+    cam = rb.rtiow_camera(320, 180, 48, 50)
+    want = ob.render(host, cam, threads=8)
+    for kw in (dict(), dict(stack_levels=3), dict(stack_levels=3, pass_spp=16), dict(stack_levels=4, primary_visibility=-1), dict(sphere_only_kernel=-1, stack_levels=3)):
+        times = {}
+        for resume in (0, -1):
+            dev = rb.DeviceScene(host, device=0, honour_env=False, resume_flagged=resume, **kw)
+            dev.render_to_host(cam)
+            fb, t = dev.render_to_host(cam)
+            assert t.guarded == 1 and t.flagged_samples > 0
+            assert_same_frame(fb, want, f"resume_flagged={resume}, {kw}")
+            times[resume] = (t.rework_ms, t.flagged_samples)
+        # (which samples a short stack flags depends on which lanes share a wave's leaf steps — a few in 200 000 differ from run to run)
+        assert abs(times[0][1] - times[-1][1]) <= 0.01 * times[0][1]
+
+
 def test_candidate_lists_are_reused_for_the_same_view(rtiow):
     """The per-pixel candidate lists and the fetch order are kept with the handle: a call with the same camera, image, shard and
     tree on the same stream (the next batch of a progressive render) does not make them again, any other call does — frames are the
