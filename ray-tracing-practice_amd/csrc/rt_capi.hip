@@ -55,6 +55,9 @@ int env_int(const char *name, int fallback) {
 // pass is the only large allocation of a scene handle and is grown on demand to what the frames actually need: 12.4 GB for
 // one 1920x1080x500-spp pass.  A smaller budget only cuts the frame into more passes: 4 GiB → 3 passes, 1.9 % slower
 // (each extra pass costs the drain of a trace launch and one more re-walk launch, ≈1.7 ms).
+#ifndef RTP_BY_PIXEL_MIN
+#define RTP_BY_PIXEL_MIN 96         /* samples per pixel and pass from which the primary-visibility pass takes a wave per PIXEL (configs[4], passes of 125: 10.6 instead of 11.9 ms; S-rtiow at 100 spp: 1.84 vs 1.91) */
+#endif
 constexpr uint64_t kWorkspaceShareOfDevice = 16;
 constexpr uint64_t kSampleBytes = 12;        // one radiance record of the slab
 
@@ -1285,7 +1288,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         if (prim) {
             // primary visibility of this pass's samples: (hit distance, primitive) into each sample's slot of the slab
             int pgrid = sc->num_cus * 8;                            // 256-thread workgroups: 8 waves per SIMD
-            const bool by_pixel = P.pass_count >= 128;              // a wave per pixel once a pixel fills it at least twice
+            const bool by_pixel = P.pass_count >= RTP_BY_PIXEL_MIN;  // a wave per pixel once a pixel (nearly) fills it twice
             const uint32_t units = by_pixel ? (num_pixels + 3u) / 4u : (P.total_work + 255u) / 256u;
             if ((uint32_t)pgrid > units) pgrid = (int)units;
             if (by_pixel) {

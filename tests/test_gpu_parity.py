@@ -280,7 +280,7 @@ def test_sky_pixels_and_the_fetch_order(config_scene):
     first (rt_primary.hip.inc, order_* kernels); at the end of a pass the waves of a workgroup take what the others still
     hold.  Frames against the oracle where those paths have their corners: nothing but sky (no pixel for the trace kernel),
     no sky at all, sky with a background of negative zeros (0 + 1 * -0 is +0), fewer pixels than one block of the sort, more
-    samples than pixels, both primary kernels (passes under and over 128 samples), several passes, a row shard, a tile."""
+    samples than pixels, both primary kernels (passes under and over 96 samples), several passes, a row shard, a tile."""
     host = rb.HostScene.rtiow()
     dev = rb.DeviceScene(host, device=0, honour_env=False)
     sky = (0.7, 0.8, 1.0)
@@ -690,7 +690,7 @@ def test_distance_aware_margins():
 
 def test_distance_aware_margins_with_the_by_pixel_primary_pass():
     """the combination a big scene rendered in few big passes takes by default — distance-aware margins (kDyn
-    kernels) x the primary-visibility pass in its by-pixel form (primary_pixel_kernel: passes of 128 samples per pixel or more),
+    kernels) x the primary-visibility pass in its by-pixel form (primary_pixel_kernel: passes of 96 samples per pixel or more),
     with and without planes — against the oracle on whole small frames: S-rtiow with the margins forced, 3 000 tiny spheres
     spread wide (alone, and with quads, ellipses and triangles among them), and a 130-spp row band of S-100k."""
     host = rb.HostScene.rtiow()
