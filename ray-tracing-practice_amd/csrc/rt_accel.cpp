@@ -702,7 +702,7 @@ void Packer::pair_tables() {
         return (c & 1) ? plane_box[static_cast<size_t>(c >> 1)] : sphere_box[static_cast<size_t>(c >> 1)];
     };
     out.num_internal = static_cast<int32_t>(bnodes.size());
-    // (every inner node of a tree built here has two children — step_pair_dyn relies on it; the caller-topology tree of
+    // (every inner node of a tree built here has two children — step_pair_par relies on it; the caller-topology tree of
     // TreeMode::Reference may carry untyped leaves as empty slots, and no guarded kernel walks that one)
     out.full_pairs = true;
     for (const BuildNode &b : bnodes)

@@ -257,24 +257,6 @@ rt_status upload(const std::vector<T> &host, void **dev) {
     return RT_OK;
 }
 
-// step_pair_dyn (rt_kernel.hip.inc) adds a record's 32-bit byte offset to the LOW word of the binary16 pair table's address:
-// the table must not straddle a 4 GiB line.  One that does (a few MB in a 4 GiB window: one allocation in a thousand) is
-// moved — the replacement is allocated while the original still holds its address.
-rt_status settle_table(float4 **table, size_t bytes) {
-    auto straddles = [bytes](const void *p) { return (((uintptr_t)p & 0xffffffffull) + bytes) > 0x100000000ull; };
-    std::vector<void *> bad;
-    rt_status st = RT_OK;
-    while (*table && bytes && straddles(*table)) {
-        void *fresh = nullptr;
-        if (bad.size() >= 8 || hipMalloc(&fresh, bytes) != hipSuccess) { st = fail(RT_ERR_OUT_OF_MEMORY, "no placement of the pair table inside one 4 GiB window"); break; }
-        if (hipMemcpy(fresh, *table, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(fresh); st = fail(RT_ERR_HIP, "copy of the pair table failed"); break; }
-        bad.push_back(*table);
-        *table = (float4 *)fresh;
-    }
-    for (void *b : bad) (void)hipFree(b);
-    return st;
-}
-
 // Reciprocal for div_magic(): exact quotients for every n <= n_max (checked, not assumed).
 bool make_magic(uint32_t d, uint64_t n_max, rtk::Magic &g) {
     if (d == 0) return false;
@@ -419,10 +401,6 @@ rt_status repack_for_camera(rt_scene *sc, const float cam[3], hipStream_t stream
     if ((st = upload(pk.nodes, (void **)&nodes)) != RT_OK || (st = upload(pk.hnodes, (void **)&hnodes)) != RT_OK ||
         (st = upload(pk.wnodes, (void **)&wnodes)) != RT_OK || (st = upload(pk.whnodes, (void **)&whnodes)) != RT_OK ||
         (st = upload(pk.leaf_boxes, (void **)&leaf_boxes)) != RT_OK || (st = upload(pk.plane_leaf_boxes, (void **)&plane_leaf_boxes)) != RT_OK) {
-        (void)hipFree(nodes); (void)hipFree(hnodes); (void)hipFree(wnodes); (void)hipFree(whnodes); (void)hipFree(leaf_boxes); (void)hipFree(plane_leaf_boxes);
-        return st;
-    }
-    if ((st = settle_table(&hnodes, (size_t)pk.num_internal * 32)) != RT_OK) {
         (void)hipFree(nodes); (void)hipFree(hnodes); (void)hipFree(wnodes); (void)hipFree(whnodes); (void)hipFree(leaf_boxes); (void)hipFree(plane_leaf_boxes);
         return st;
     }
@@ -597,7 +575,6 @@ rt_status rt_scene_create_ex(const rt_scene_desc *desc, const rt_config *user_cf
         if ((st = upload(pk.whnodes, (void **)&sc->whnodes)) != RT_OK) return bail(st);
         sc->num_wide = pk.num_wide; sc->num_top_wide = pk.num_top_wide; sc->wroot = pk.wroot; sc->wide_depth = pk.wide_depth;
     }
-    if ((st = settle_table(&sc->hnodes, (size_t)pk.num_internal * 32)) != RT_OK) return bail(st);
     if ((st = upload(pk.tnodes, (void **)&sc->tnodes)) != RT_OK) return bail(st);
     sc->num_tnodes = pk.num_tnodes;
     if ((st = upload(pk.xnodes, (void **)&sc->xnodes)) != RT_OK) return bail(st);
@@ -860,7 +837,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // (step_wide_par tells an empty child slot by its box — the finite inverted (65504, -65504) of the binary16 table — which holds
         // while the growth stays below 65504: it never exceeds dyn_k x (twice the radius every ray origin lies within)^2)
         const double growth_max = (double)sc->guard.dyn_k * 4.0 * (double)sc->guard.origin_radius * (double)sc->guard.origin_radius;
-        const bool wide_par_scene = sc->guard.dyn_k > 0.0f && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0 && growth_max < 16384.0;
+        const bool wide_par_scene = sc->guard.dyn_k > 0.0f && growth_max < 16384.0;
         return sc->whnodes != nullptr && sc->num_wide > 0 && !want_wavefront && (cfg.wide_nodes > 0 || (cfg.wide_nodes == 0 && wide_par_scene));
     };
     bool wide = wide_nodes_wanted();
@@ -921,7 +898,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // … and of the walk through L1 / L2 for scenes with distance-aware margins (step_pair_par on pair nodes: the 4-wide step does
         // not fit 64 registers): sphere-only scenes beyond what LDS holds — S-rtiow x 785 … 99 857 spheres: +7 … +10 % over the general
         // build on 4-wide nodes (8.1 / 7.7 / 6.7 / 3.9 against 7.5 / 7.2 / 6.2 / 3.6 Gsamples/s; tools/size_sweep.py)
-        const bool dyn_global_scene = sc->guard.dyn_k > 0.0f && !want_wavefront && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0 && cfg.wide_nodes <= 0;
+        const bool dyn_global_scene = sc->guard.dyn_k > 0.0f && !want_wavefront && cfg.wide_nodes <= 0;
         if (!simple && dyn_global_scene && cfg.sphere_only_kernel >= 0 && P.num_planes == 0 && sc->tex_data == nullptr && P.leaf_boxes == nullptr &&
             cfg.workgroups_per_cu == 0 && !sc->absorbing_glass) {
             simple = true;
@@ -945,17 +922,17 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // full stack, two workgroups per CU whatever the size of the tree).  The LDS-resident form of that walk lost on every
         // random scene it was tried on — tables of a thousand nodes leave room for one workgroup per CU or for a stack of four,
         // and the rays a short stack hands to the exact walk cost more than L1 does: tools/dyn_probe.py, docs/LOG.md round 4.
-        const bool dyn_global = sc->guard.dyn_k > 0.0f && !want_wavefront && RTP_DYN_ROTATE != 0 && RTP_DYN_PARAM != 0;
+        const bool dyn_global = sc->guard.dyn_k > 0.0f && !want_wavefront;
         fast.in_lds = cfg.scene_in_lds != 0 && !dyn_global;
         if (fast.in_lds) {
             fast.stack_levels = levels_for(table_bytes, fast.wgs_per_cu);
             while (fast.wgs_per_cu > 1 && fast.stack_levels < min_levels) fast.stack_levels = levels_for(table_bytes, --fast.wgs_per_cu);
             if (fast.stack_levels < min_levels) fast.in_lds = false;
         }
-        // (step_pair_dyn / step_pair_par, the walk of big scenes with distance-aware margins, keep a sentinel in level 0 — one level
-        // more for the same twelve entries — and step_pair_par two rows of per-ray values behind the stack)
-        const bool dyn_pair = !fast.in_lds && sc->guard.dyn_k > 0.0f && !want_wavefront && RTP_DYN_ROTATE != 0;       // (pair nodes, or their 4-wide form: step_wide_par)
-        const int32_t extra_rows = dyn_pair ? (RTP_DYN_PARAM != 0 ? 2 : 0) : 0;
+        // (step_pair_par / step_wide_par, the walks of scenes with distance-aware margins, keep a sentinel in level 0 — one level
+        // more for the same twelve entries — and two rows of per-ray values behind the stack)
+        const bool dyn_pair = !fast.in_lds && dyn_global;       // (pair nodes, or their 4-wide form)
+        const int32_t extra_rows = dyn_pair ? 2 : 0;
         if (!fast.in_lds) {
             // tables through L1/L2: a 12-entry stack per lane (deeper ones are rare enough to flag), the rest of
             // the workgroup's LDS share holds the top of the tree
@@ -968,8 +945,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         }
         if (const int forced = cfg.stack_levels) fast.stack_levels = forced + extra_rows < fast.stack_levels ? forced + extra_rows : fast.stack_levels;
         if (fast.stack_levels - extra_rows < (want < 2 ? want : 2)) guarded = false;
-        // (step_pair_par reads every record through L1 / L2: RTP_DYN_TOP)
-        if (!fast.in_lds && cfg.lds_treelet && !(dyn_pair && RTP_DYN_PARAM != 0 && (RTP_DYN_TOP == 0 || wide))) {
+        // (the walks of scenes with distance-aware margins read every record through L1 / L2: no treelet)
+        if (!fast.in_lds && cfg.lds_treelet && !dyn_pair) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
             const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);
             const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;
@@ -1316,7 +1293,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             const bool octant_launch = (RTP_OCTANT != 0) && fast.in_lds && !wide && !wavefront && !dyn;
             if (octant_launch && sc->cfg.k_inner <= 0) P.k_inner = 32;
             if (octant_launch && sc->cfg.k_shade <= 0) P.k_shade = 52;
-            // big scene with distance-aware margins (tables through L1/L2, step_pair_dyn): a block of pair steps costs memory round
+            // scene with distance-aware margins (records through L1/L2, step_pair_par / step_wide_par): a block of steps costs memory round
             // trips on top of its instructions — worth starting only for a nearly full wave (S-100k, swept 16-52 x 44-56: +4 %)
             const bool big_dyn_launch = dyn && !fast.in_lds && !wavefront;
             if (big_dyn_launch && sc->cfg.k_inner <= 0) P.k_inner = 48;
@@ -1365,13 +1342,9 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
                 else HIP_TRY(launch(rtk::render_kernel<false, false, true, true>, P, wgs, fast.lds_bytes));
 #ifdef RTP_DEV_BUILD
             } else if (wide) {
-                if (dyn) HIP_TRY(launch(rtk::render_kernel<true, false, true, true>, P, wgs, fast.lds_bytes));
-                else if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
+                if (fast.in_lds) HIP_TRY(launch(rtk::render_kernel<true, false, false, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch(rtk::render_kernel<false, false, false, true>, P, wgs, fast.lds_bytes));
 #endif
-            } else if (dyn && fast.in_lds) {       // (only with RTP_DYN_PARAM or RTP_DYN_ROTATE off: developer variants)
-                if (prim) HIP_TRY(launch(rtk::render_kernel<true, false, true, false, false, true>, P, wgs, fast.lds_bytes));
-                else HIP_TRY(launch(rtk::render_kernel<true, false, true>, P, wgs, fast.lds_bytes));
             } else if (dyn && simple) {      // sphere-only scenes beyond what LDS holds: step_pair_par at 64 registers, 8 waves per SIMD
                 if (prim) HIP_TRY(launch_simple(rtk::render_kernel<false, false, true, false, true, true>, P, wgs, fast.lds_bytes));
                 else HIP_TRY(launch_simple(rtk::render_kernel<false, false, true, false, true>, P, wgs, fast.lds_bytes));
