@@ -235,10 +235,10 @@ typedef struct rt_config {
                                      without any per-sample work, the others are traced expensive ones first — the same frame bit for
                                      bit; -1: camera rays walk the tree */
     int32_t  guard_bail_share;    /* what the guarded walk may cost before it steps aside, as the share of flagged samples in 1/256ths
-                                     (0 = default: 64, i.e. 25 % — measured break-even is 10-15 %, a disaster starts at 40 %; -1: never).
-                                     Inside a pass: once the flagged share of the samples handed out so far exceeds it AND a quarter of
-                                     that share of the whole pass is on the list, the waves stop fetching and the exact walk renders the
-                                     WHOLE pass (bounded loss: what the guarded launch had done).  Between frames: a frame that abandoned a
+                                     (0 = default: 64, i.e. 25 % — measured break-even is 21-26 % of a frame's samples; -1: never).
+                                     Inside a pass: once the flagged share of the samples handed out so far exceeds it AND 9.4 % of the
+                                     whole pass is on the list AND the pass is still in its first quarter, the waves stop fetching and
+                                     the exact walk renders the WHOLE pass (bounded loss: what the guarded launch had done).  Between frames: a frame that abandoned a
                                      pass, or flagged more than this share overall, makes the handle use the exact walk from then on —
                                      found at the next render call from what the previous one left in host memory, no rt_last_timing
                                      needed.  Below it RT_TRAVERSAL_AUTO decides by measurement (see traversal) */

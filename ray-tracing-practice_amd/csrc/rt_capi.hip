@@ -72,13 +72,20 @@ constexpr int kTimedPasses = 64;        // trace launches individually timed per
 #endif
 constexpr int kQueueWork = 0, kQueueRework = kMaxPasses, kQueueFlag = 2 * kMaxPasses, kQueueStats = 3 * kMaxPasses;
 constexpr int kQueueDirty = 3 * kMaxPasses + 16;      // per pass: pixels with a flagged sample (overlapped re-walk)
-constexpr int kQueueAbandon = 4 * kMaxPasses + 16;    // per pass: the guarded launch gave up part-way (render_kernel, flag_write)
-constexpr int kQueueWords = 5 * kMaxPasses + 16;
+constexpr int kQueueAbandon = 4 * kMaxPasses + 16;    // per pass: the guarded launch gave up part-way (render_kernel, flag_reserve)
+constexpr int kQueueHoles = 5 * kMaxPasses + 16;      // per pass: slots of the flagged-sample list reserved and never filled (flag_stage_drain)
+constexpr int kQueueWords = 6 * kMaxPasses + 16;
+static_assert(kQueueHoles - kQueueFlag == (int)rtk::kFlagHolesWords, "the holes word sits where the kernels look for it");
+// LDS of a guarded kernel that is neither tables nor stacks nor work ranges: its constants block and, behind it, two words per wave
+// (of at most sixteen) for the wave's chunk of the flagged-sample list (rt_kernel.hip.inc: fill_consts, flag_collect)
+constexpr uint32_t kGuardBlockBytes = 16u * (uint32_t)rtk::kConstRows + (uint32_t)(rtk::kSimpleBlock / rtk::kWave) * 8u;
 // What a render call leaves for the NEXT one to read (rt_scene::feedback): per pass the flagged count and the abandon word, copied
 // to pinned host memory at the end of the call, with an event — the handle's decision to step aside from the guarded walk needs no
 // rt_last_timing and no synchronisation of the caller's.
 constexpr int kFeedbackSlots = 4;
 constexpr uint32_t kDefaultBailShare = 64;            // of 256: 25 % (rt_config.guard_bail_share)
+constexpr uint32_t kDefaultBailLatest = 2;            // of 8: a pass is given up in its first quarter or not at all
+constexpr uint32_t kDefaultBailFloor = 96;            // of 1024: 9.4 % of the pass on the list before it is given up (swept with kDefaultBailLatest: docs/LOG.md round 4)
 constexpr uint32_t kExploreShare = 1;                 // of 256: a guarded frame that flagged more than 0.4 % is timed against an exact one …
 constexpr float kExploreOverhead = 0.15f;             // … and so is one that spent more than this share of its time outside the trace launch
 
@@ -155,6 +162,15 @@ uint32_t bail_share_of(const rt_config &cfg) {      // in 1/256ths; 0 = never
     if (cfg.guard_bail_share < 0) return 0u;
     const uint32_t s = cfg.guard_bail_share == 0 ? kDefaultBailShare : (uint32_t)cfg.guard_bail_share;
     return s > 255u ? 255u : s;
+}
+// … and what must be on the list before a pass is given up, in 1/1024ths of the pass (RTP_BAIL_FLOOR: for measurements)
+uint32_t bail_floor() {
+    static const uint32_t f = [] { const int v = env_int("RTP_BAIL_FLOOR", (int)kDefaultBailFloor); return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v); }();
+    return f;
+}
+uint32_t bail_latest() {          // … and until when, in eighths of the pass (RTP_BAIL_LATEST)
+    static const uint32_t f = [] { const int v = env_int("RTP_BAIL_LATEST", (int)kDefaultBailLatest); return (uint32_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();
+    return f;
 }
 // rt_timing is an out-structure of the caller's size (include/rtp_amd.h)
 rt_status timing_check(const rt_timing *t) {
@@ -694,7 +710,8 @@ rt_status judge_frame(rt_scene *sc, rt_scene::Feedback &f) {
     if (f.guarded) {
         uint64_t total = 0;
         uint32_t gave_up = 0;
-        for (int p = 0; p < f.passes; ++p) { total += f.host[p]; gave_up += f.host[kMaxPasses + p] != 0u ? 1u : 0u; }
+        // (list slots handed out less the ones nobody filled: rt_kernel.hip.inc, flag_stage_drain)
+        for (int p = 0; p < f.passes; ++p) { total += f.host[p] - f.host[2 * kMaxPasses + p]; gave_up += f.host[kMaxPasses + p] != 0u ? 1u : 0u; }
         if (share != 0u && (gave_up != 0u || total * 256u > (uint64_t)share * f.samples)) sc->guard_paused = true;
         if (gave_up == 0u) sc->guarded_ns_per_sample = ns;
         // worth a measurement?  many flagged samples, or much time spent on what the exact walk does not need (the primary pass,
@@ -737,7 +754,7 @@ rt_status acquire_feedback(rt_scene *sc, rt_scene::Feedback **out) {
         if (const rt_status st = judge_frame(sc, f)) return st;
     }
     if (!f.host) {
-        HIP_TRY(hipHostMalloc((void **)&f.host, 2 * kMaxPasses * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&f.host, 3 * kMaxPasses * sizeof(uint32_t), hipHostMallocDefault));
         HIP_TRY(hipEventCreate(&f.start));
         HIP_TRY(hipEventCreate(&f.done));
     }
@@ -845,7 +862,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
     // the sphere-only build of the octant walk (render_kernel<…, kSimple>): 1024-thread workgroups, 8 waves per SIMD
     bool simple = false;
-    uint32_t flag_stage = 0;       // words per wave of the LDS stage for flagged samples
+    uint32_t flag_stage = 0;       // LDS words per wave for its chunk of the flagged-sample list (rt_kernel.hip.inc, flag_collect): 2, or 0
     if (guarded) {
         // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
         // spheres for origins within sqrt(d0_sq) of their cluster: a camera outside either gets the tree re-packed
@@ -873,7 +890,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // for the pair walk with static margins (rt_kernel.hip.inc, step_octant)
         const bool octant = (RTP_OCTANT != 0) && !wide && !want_wavefront && !(sc->guard.dyn_k > 0.0f);
         uint64_t table_bytes = ((wide ? (uint64_t)P.num_wide * 7 : (uint64_t)P.num_internal * (octant ? 5 : 4)) + prim_f4) * 16 +
-                               (!want_wavefront ? 16u * rtk::kConstRows : 0u);      // + the guarded kernels' constants block
+                               (!want_wavefront ? kGuardBlockBytes : 0u);      // + the guarded kernels' constants block
         const int32_t deepest = wide ? 3 * sc->wide_depth : sc->tree_depth;          // a wide node leaves up to three children waiting
         const int32_t want = deepest + 1 > 2 ? deepest + 1 : 2;       // never overflows
         uint32_t per_level = gblock * 4u;
@@ -889,7 +906,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             if (fit >= 6 || fit >= want) {          // at least the sentinel + 5 levels: below that the re-walk launch eats the gain
                 gblock = (uint32_t)rtk::kSimpleBlock;
                 gwgs_per_cu = rtk::kSimpleWaves * 256 / rtk::kSimpleBlock;
-                table_bytes = simple_bytes + ((uint64_t)(rtk::kSimpleBlock / rtk::kWave) * 8u - pool_bytes) + 16 * rtk::kConstRows;      // + the four extra waves' work ranges + the constants block
+                table_bytes = simple_bytes + ((uint64_t)(rtk::kSimpleBlock / rtk::kWave) * 8u - pool_bytes) + kGuardBlockBytes;      // + the four extra waves' work ranges + the constants block
                 per_level = gblock * 4u;
             } else {
                 simple = false;
@@ -938,7 +955,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             // the workgroup's LDS share holds the top of the tree
             fast.wgs_per_cu = gwgs_per_cu;
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
-            const int64_t fit = budget > pool_bytes + pool_extra + 16u * rtk::kConstRows ? (int64_t)((budget - pool_bytes - pool_extra - 16u * rtk::kConstRows) / per_level) : 0;
+            const int64_t fit = budget > pool_bytes + pool_extra + kGuardBlockBytes ? (int64_t)((budget - pool_bytes - pool_extra - kGuardBlockBytes) / per_level) : 0;
             // (the 4-wide walk leaves up to three children of a node waiting, and LDS holds nothing but the stacks: twenty entries)
             const int32_t cap = (dyn_pair ? (wide ? 21 : 13) : 12) + extra_rows;
             fast.stack_levels = (int32_t)std::min<int64_t>(std::min<int64_t>(fit, want + extra_rows), cap);
@@ -948,23 +965,16 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         // (the walks of scenes with distance-aware margins read every record through L1 / L2: no treelet)
         if (!fast.in_lds && cfg.lds_treelet && !dyn_pair) {
             const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
-            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? 16u * rtk::kConstRows : 0u);
+            const uint64_t used = pool_bytes + (uint64_t)fast.stack_levels * per_level + (!want_wavefront ? kGuardBlockBytes : 0u);
             const int64_t fit = budget > used ? (int64_t)((budget - used) / (wide ? 64 : 32)) : 0;
             const int32_t top_have = wide ? sc->num_top_wide : sc->num_top_pairs;
             fast.num_top = (int32_t)(fit < top_have ? fit : top_have);
         }
         if ((!fast.in_lds && !dyn_global_scene) || fast.wgs_per_cu != gwgs_per_cu) simple = false;      // (cannot happen after the fit test above; the general kernel is always right)
-        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + pool_extra + (!want_wavefront ? 16u * rtk::kConstRows : 0u)) + pool_bytes +
+        fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + pool_extra + (!want_wavefront ? kGuardBlockBytes : 0u)) + pool_bytes +
                                     (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
-        // what is left of the workgroup's LDS share stages flagged samples per wave (render_kernel, flag_append): 32, 16 or 8 words
-        if (!want_wavefront) {
-            const uint64_t budget = kLdsLimit / (uint64_t)fast.wgs_per_cu;
-            const uint32_t gwaves = gblock / (uint32_t)rtk::kWave;
-            for (uint32_t words = 32u; words >= 8u && flag_stage == 0u; words >>= 1)
-                if ((uint64_t)fast.lds_bytes + (uint64_t)gwaves * words * 4u <= budget) flag_stage = words;
-            fast.lds_bytes += gwaves * flag_stage * 4u;
-        }
+        if (!want_wavefront) flag_stage = 2u;          // (the wave's chunk of the flagged-sample list: inside kGuardBlockBytes)
     }
     bool use_queue = false;
 #ifdef RTP_DEV_QUEUE_KERNEL
@@ -1325,6 +1335,8 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             P.flag_stage = flag_stage;
             // in-launch bail-out (not for a caller who insists on the guarded walk, nor for the experimental kernels)
             P.bail_share = (cfg.guard_keep || wavefront) ? 0u : bail_share_of(cfg);
+            P.bail_floor = bail_floor();
+            P.bail_latest = bail_latest();
             P.abandon = P.bail_share != 0u ? sc->queue + kQueueAbandon + pass : nullptr;
             rtk::fill_consts(P);          // (everything the constants block copies is final now)
             if (wavefront) {
@@ -1436,6 +1448,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         if (guarded) {
             HIP_TRY(hipMemcpyAsync(f.host, sc->queue + kQueueFlag, (size_t)passes * 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(f.host + kMaxPasses, sc->queue + kQueueAbandon, (size_t)passes * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(f.host + 2 * kMaxPasses, sc->queue + kQueueHoles, (size_t)passes * 4, hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(hipEventRecord(f.done, stream));
         f.pending = true;
@@ -1507,12 +1520,13 @@ rt_status rt_last_timing(rt_scene *sc, rt_timing *timing) {
         sc->last.rework_ms = rework;
         sc->last.primary_ms = sc->last.primary_visibility ? primary : 0.0f;
         if (sc->last.guarded) {
-            std::vector<uint32_t> counts((size_t)sc->last_passes), gave_up((size_t)sc->last_passes);
+            std::vector<uint32_t> counts((size_t)sc->last_passes), gave_up((size_t)sc->last_passes), holes((size_t)sc->last_passes);
             HIP_TRY(hipMemcpy(counts.data(), sc->queue + kQueueFlag, counts.size() * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(holes.data(), sc->queue + kQueueHoles, holes.size() * 4, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(gave_up.data(), sc->queue + kQueueAbandon, gave_up.size() * 4, hipMemcpyDeviceToHost));
             uint64_t total = 0;
             uint32_t abandoned = 0;
-            for (size_t p = 0; p < counts.size(); ++p) { total += counts[p]; abandoned += gave_up[p] != 0u ? 1u : 0u; }
+            for (size_t p = 0; p < counts.size(); ++p) { total += counts[p] - holes[p]; abandoned += gave_up[p] != 0u ? 1u : 0u; }
             sc->last.flagged_samples = total;
             sc->last.abandoned_passes = abandoned;
         }

@@ -71,6 +71,13 @@ def main():
                     print(f"{what:22s} frame {k}: {t.kernel_ms:7.2f} ms guarded {t.guarded} abandoned {t.abandoned_passes} paused {t.guard_paused} trace {t.trace_ms:6.2f} re-walk {t.rework_ms:6.2f} primary "
                           f"{t.primary_ms:5.2f} (on {t.primary_visibility}) flagged {t.flagged_samples} lds {t.lds_bytes} in_lds {t.scene_in_lds} wgs {t.num_workgroups} x {t.workgroup_size} "
                           f"dyn {t.guard_dynamic} simple {t.sphere_only} vgprs {t.trace_vgprs}", flush=True)
+                    if os.environ.get("STATS") and k == 0:          # an RTP_STATS build (RTP_AMD_LIB): the frame's step counters, both launches together
+                        import ctypes as C
+                        out = (C.c_uint32 * 16)(); rb.amd_lib().rt_debug_read_stats(d._h, out)
+                        ns = W * H * spp
+                        print("    " + "  ".join(f"{n} wave-steps/sample {out[2 * i] / ns:.4f} lanes {out[2 * i + 1] / max(out[2 * i], 1):.3f} kticks {out[8 + i]}"
+                                                 for i, n in enumerate(["pair", "leaf", "shade", "vote"])))
+                        print(f"    why flagged: full stack {out[12]}, exact tie {out[13]}, final check / Schlick window {out[14]}", flush=True)
                 d.close()
             continue
         n_samples = W * H * spp
@@ -95,7 +102,7 @@ def main():
         print(f"scene {trial:2d}: {sph.shape[0]:5d} spheres {pl.shape[0]:2d} planes spread {spread:5.1f} ({reason}) | default frames: "
               + ", ".join(f"{t.kernel_ms:7.2f} ms ({'guarded' if t.guarded else 'exact'}{', abandoned' if t.abandoned_passes else ''})" for _, t in frames)
               + f" | flagged {100.0 * t0.flagged_samples / n_samples:7.4f} % trace {t0.trace_ms:6.2f} re-walk {t0.rework_ms:6.2f} primary {t0.primary_ms:5.2f} | exact {te.kernel_ms:7.2f} ms"
-              f" | forced guarded {tg.kernel_ms:7.2f} ms, flagged {100.0 * tg.flagged_samples / n_samples:7.4f} % | ratios " + " ".join(f"{r:4.2f}" for r in ratios)
+              f" | forced guarded {tg.kernel_ms:7.2f} ms (trace {tg.trace_ms:.2f} re-walk {tg.rework_ms:.2f}), flagged {100.0 * tg.flagged_samples / n_samples:7.4f} % | ratios " + " ".join(f"{r:4.2f}" for r in ratios)
               + ("  <-- above 1.3" if max(ratios) > 1.3 else "") + f" | differing pixels {bad}", flush=True)
     print(f"TOTAL seed {seed}: {count} scenes, {total_samples / 1e9:.2f} G samples per frame set, differing pixels {total_bad}, worst default/exact ratio {worst:.2f}, "
           f"default frames above 1.3: {over}")

@@ -380,7 +380,7 @@ static void leafk_ray(const ray *r, float c_ref, int prim_ref) {
  * the ray buy?  Its own SAH tree (TOPBIG=1: without the spheres whose leaf box covers more than half of the root's surface —
  * those are tested before the walk, so the walk starts with their hit as its `closest`), node boxes as the kernel holds them
  * (HALF16=1: rounded outward to binary16), and the distance-aware growth by one of three rules:
- *   GROW=1  dyn_k D^2, D = distance from the origin to the farthest corner of the UNION of the two children (step_pair_dyn)
+ *   GROW=1  dyn_k D^2, D = distance from the origin to the farthest corner of the UNION of the two children (round 3's walk, since removed)
  *   GROW=4  the kernel's rule (step_pair_par): k (T |d| + sqrt(3) (r_max + e))^2, T = the exit parameter of the (grown, clipped) box the
  *           node was entered through, e the growth that box was tested with — every accepted hit below the node lies on the ray inside
  *           that box, so T |d| bounds its distance; a node off the stack gets the ray's own bound (corner of the tree / the hit in hand).
