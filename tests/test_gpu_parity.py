@@ -1116,6 +1116,23 @@ def test_a_pass_that_flags_a_third_of_its_samples_appends_them_in_chunks():
     assert abs(int(tk2.flagged_samples) - int(tk.flagged_samples)) < 0.001 * total
     assert_same_frame(fb, want, "guarded walk kept, second frame")
 
+    # … the same in three passes (each launch starts its waves' chunks afresh, each pass has its own counters), on a row shard, on a tile
+    _, cam3, _ = _stress_scene(22, 32, 192, 640, 360)                  # (the same view at a quarter of the pixels, four times the samples)
+    want3, _ = exact.render_to_host(cam3)
+    many = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_GUARDED, guard_keep=1, workspace_bytes=640 * 360 * 12 * 64)
+    fb, tm = many.render_to_host(cam3)
+    assert tm.trace_launches == 3 and tm.abandoned_passes == 0
+    assert 0.3 * total < tm.flagged_samples < 0.4 * total, tm.flagged_samples / total
+    assert_same_frame(fb, want3, "three passes")
+    shard = rb.Shard(8, 3, 1)
+    part, ts = kept.render_to_host(cam, shard)
+    rows_of_shard = np.concatenate([np.arange(b, min(b + 8, 720)) for b in range(8, 720, 24)])
+    assert ts.flagged_samples > 0.2 * len(rows_of_shard) * 1280 * 48
+    assert_same_frame(part, want[rows_of_shard], "row shard 1 of 3")
+    tile, tt = kept.render_tile_to_host(cam, 333, 201, 517, 263)
+    assert tt.flagged_samples > 0
+    assert_same_frame(tile, want[201:201 + 263, 333:333 + 517], "tile")
+
     dev = rb.DeviceScene(host, device=0, traversal=rb.TRAVERSAL_AUTO, guard_keep=0)                    # the defaults
     fb, t = dev.render_to_host(cam)
     assert t.guarded == 1 and t.abandoned_passes == 1 and t.guard_paused == 1
