@@ -73,7 +73,7 @@ constexpr int kTimedPasses = 64;        // trace launches individually timed per
 constexpr int kQueueWork = 0, kQueueRework = kMaxPasses, kQueueFlag = 2 * kMaxPasses, kQueueStats = 3 * kMaxPasses;
 constexpr int kQueueDirty = 3 * kMaxPasses + 16;      // per pass: pixels with a flagged sample (overlapped re-walk)
 constexpr int kQueueAbandon = 4 * kMaxPasses + 16;    // per pass: the guarded launch gave up part-way (render_kernel, flag_reserve)
-constexpr int kQueueHoles = 5 * kMaxPasses + 16;      // per pass: slots of the flagged-sample list reserved and never filled (flag_stage_drain)
+constexpr int kQueueHoles = 5 * kMaxPasses + 16;      // per pass: slots of the flagged-sample list reserved and never filled (flag_chunk_drain)
 constexpr int kQueueWords = 6 * kMaxPasses + 16;
 static_assert(kQueueHoles - kQueueFlag == (int)rtk::kFlagHolesWords, "the holes word sits where the kernels look for it");
 // LDS of a guarded kernel that is neither tables nor stacks nor work ranges: its constants block and, behind it, two words per wave
@@ -710,7 +710,7 @@ rt_status judge_frame(rt_scene *sc, rt_scene::Feedback &f) {
     if (f.guarded) {
         uint64_t total = 0;
         uint32_t gave_up = 0;
-        // (list slots handed out less the ones nobody filled: rt_kernel.hip.inc, flag_stage_drain)
+        // (list slots handed out less the ones nobody filled: rt_kernel.hip.inc, flag_chunk_drain)
         for (int p = 0; p < f.passes; ++p) { total += f.host[p] - f.host[2 * kMaxPasses + p]; gave_up += f.host[kMaxPasses + p] != 0u ? 1u : 0u; }
         if (share != 0u && (gave_up != 0u || total * 256u > (uint64_t)share * f.samples)) sc->guard_paused = true;
         if (gave_up == 0u) sc->guarded_ns_per_sample = ns;
@@ -862,7 +862,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
     int gwgs_per_cu = (want_wavefront ? RTP_WF_MIN_WAVES : RTP_MIN_WAVES) * 256 / (int)gblock;
     // the sphere-only build of the octant walk (render_kernel<…, kSimple>): 1024-thread workgroups, 8 waves per SIMD
     bool simple = false;
-    uint32_t flag_stage = 0;       // LDS words per wave for its chunk of the flagged-sample list (rt_kernel.hip.inc, flag_collect): 2, or 0
+    uint32_t flag_chunk_words = 0;       // LDS words per wave for its chunk of the flagged-sample list (rt_kernel.hip.inc, flag_collect): 2, or 0
     if (guarded) {
         // The margins were sized for ray origins within origin_radius of origin_center, and those of the small
         // spheres for origins within sqrt(d0_sq) of their cluster: a camera outside either gets the tree re-packed
@@ -974,7 +974,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         fast.lds_bytes = (uint32_t)((fast.in_lds ? table_bytes : (uint64_t)fast.num_top * (wide ? 64 : 32) + pool_extra + (!want_wavefront ? kGuardBlockBytes : 0u)) + pool_bytes +
                                     (uint64_t)fast.stack_levels * per_level);
         if (const int w = cfg.workgroups_per_cu) { if ((uint64_t)w * fast.lds_bytes <= kLdsLimit) fast.wgs_per_cu = w; }
-        if (!want_wavefront) flag_stage = 2u;          // (the wave's chunk of the flagged-sample list: inside kGuardBlockBytes)
+        if (!want_wavefront) flag_chunk_words = 2u;          // (the wave's chunk of the flagged-sample list: inside kGuardBlockBytes)
     }
     bool use_queue = false;
 #ifdef RTP_DEV_QUEUE_KERNEL
@@ -1200,7 +1200,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
         KP.stack_levels = 0;
         KP.num_top = exact.num_top;
         if (whole_pass && exact_simple) {
-            KP.flag_stage = 0;
+            KP.flag_chunk_words = 0;
             KP.bail_share = 0;
             rtk::fill_consts(KP);          // (its launch constants come from the LDS block, like the guarded sphere-only build's)
             return launch_simple_on(rtk::render_kernel<true, true, false, false, true>, KP, grid, exact_s.lds_bytes);
@@ -1332,7 +1332,7 @@ rt_status render_impl(rt_scene *sc, const rt_camera_data *cam, const rt_shard *s
             P.dirty_count = sc->queue + kQueueDirty + pass;
             P.flag_cap = (uint32_t)(sc->flag_cap < 0xffffffffu ? sc->flag_cap : 0xffffffffu);
             if (const uint32_t tiny = cfg.flag_capacity) P.flag_cap = tiny < P.flag_cap ? tiny : P.flag_cap;   // test hook: overflow path
-            P.flag_stage = flag_stage;
+            P.flag_chunk_words = flag_chunk_words;
             // in-launch bail-out (not for a caller who insists on the guarded walk, nor for the experimental kernels)
             P.bail_share = (cfg.guard_keep || wavefront) ? 0u : bail_share_of(cfg);
             P.bail_floor = bail_floor();
